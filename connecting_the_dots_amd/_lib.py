@@ -1,0 +1,49 @@
+"""ctypes binding of libctd_hip.so (the C ABI of include/ctd_hip.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libctd_hip.so")
+
+_c_int, _c_long, _c_float, _c_size_t, _vp = (ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t,
+                                             ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/ctd_hip.h one to one
+SIGNATURES = {
+    "ctd_version": (_c_int, []),
+    "ctd_status_string": (ctypes.c_char_p, [_c_int]),
+    "ctd_xcorrvol_workspace_bytes": (_c_size_t, [_c_int] * 7),
+    "ctd_xcorrvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 7 + [_vp, _c_size_t, _c_int, _vp]),
+    "ctd_xcorrvol_f64": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),
+    "ctd_argmax_disp_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_int, _vp]),
+    "ctd_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 7 + [_c_float, _vp, _c_size_t,
+                                                                                          _c_int, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (python -m connecting_the_dots_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "connecting_the_dots_amd: %s is missing -- build it with "
+                "`python -m connecting_the_dots_amd.build` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)       # AttributeError here means header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ctd_status_string(status).decode()
+        raise RuntimeError("%s failed: %s (status %d)" % (what, msg, status))

@@ -1,0 +1,91 @@
+// ctd_api.hip -- the extern "C" surface declared in include/ctd_hip.h.
+// Argument validation lives here; kernels assume validated shapes.
+#include "ctd_internal.h"
+
+using namespace ctd;
+
+extern "C" {
+
+int ctd_version(void) { return 1; }
+
+const char* ctd_status_string(int status) {
+  switch (status) {
+    case CTD_OK: return "ok";
+    case CTD_ERR_INVALID_ARG: return "invalid argument";
+    case CTD_ERR_WORKSPACE: return "workspace missing or too small";
+    case CTD_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    default: break;
+  }
+  if (status >= CTD_ERR_HIP) return hipGetErrorString((hipError_t)(status - CTD_ERR_HIP));
+  return "unknown status";
+}
+
+static bool vol_shape_ok(int frames, int C, int H, int W, int D, int bs) {
+  if (frames < 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0 || bs <= 0) return false;
+  // the reference indexes outputs with int (common_cuda.h:65-66, ext_cpu.cpp:8-9)
+  if ((double)D * H * W >= 2147483648.0) return false;
+  return true;
+}
+
+size_t ctd_xcorrvol_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo) {
+  if (!vol_shape_ok(frames, C, H, W, D, block_size)) return 0;
+  // worst case over "pattern shared" / "pattern per frame"
+  size_t exact = ncc_exact_workspace_bytes(frames, C, H, W, D, block_size, true);
+  (void)algo;
+  return exact;
+}
+
+int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
+                     int W, int D, int block_size, int algo, void* workspace, size_t workspace_bytes, int device,
+                     void* stream) {
+  if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!in0 || !in1 || !out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  if (algo == CTD_NCC_EXACT)
+    return ncc_exact_f32(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
+                         (hipStream_t)stream);
+  return CTD_ERR_UNSUPPORTED;
+}
+
+int ctd_xcorrvol_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C,
+                     int H, int W, int D, int block_size, void* workspace, size_t workspace_bytes, int device,
+                     void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!in0 || !in1 || !out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return ncc_exact_f64(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, (hipStream_t)stream);
+}
+
+int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, int device,
+                        void* stream) {
+  if (frames < 0 || D <= 0 || H <= 0 || W <= 0) return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!vol || !idx) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return argmax_disp_f32(vol, idx, best, frames, D, H, W, (hipStream_t)stream);
+}
+
+int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
+                            float* best, int frames, int C, int H, int W, int D, int block_size, int algo,
+                            float rerank_eps, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  (void)rerank_eps;
+  if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
+  if (C != 1) return CTD_ERR_UNSUPPORTED;
+  if (frames == 0) return CTD_OK;
+  if (!in0 || !in1 || !idx) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  if (algo == CTD_NCC_EXACT)
+    return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
+                                workspace_bytes, (hipStream_t)stream);
+  return CTD_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

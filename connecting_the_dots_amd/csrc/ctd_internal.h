@@ -1,0 +1,18 @@
+// ctd_internal.h -- C++ entry points behind the C ABI (one per kernel family).
+#pragma once
+#include "ctd_common.h"
+
+namespace ctd {
+
+// ncc_exact.hip
+size_t ncc_exact_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
+int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
+                  int W, int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int ncc_exact_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C, int H,
+                  int W, int D, int bs, hipStream_t stream);
+int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
+                         float* best, int frames, int H, int W, int D, int bs, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream);
+int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream);
+
+}  // namespace ctd

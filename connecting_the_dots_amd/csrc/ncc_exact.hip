@@ -1,0 +1,394 @@
+// ncc_exact.hip -- zero-mean NCC block-matching volume in REFERENCE OPERATION ORDER.
+//
+// Replaces xcorrvol_kernel / XCorrVolFunctor (torchext/ext/ext_kernel.cu:40-50,
+// torchext/ext/ext.h:120-191).  The reference runs one thread per (d,h,w) output and
+// re-reads 2*C*bs^2 taps from global memory twice per output.  Here:
+//
+//   * the per-window means / variances are hoisted: (mu0, sigma0) depend only on the
+//     pixel, (mu1, sigma1) only on (h, x = w - d) because the reference shifts the
+//     column BEFORE clamping it (ext.h:152-154).  A small pre-pass computes them with
+//     the reference's own two-pass tap order, so the bits are identical;
+//   * one thread owns one pixel, keeps its bs^2 centred taps v0 = in0 - mu0 in VGPRs
+//     and walks the disparities ND at a time; pattern rows are staged in LDS with the
+//     replicate border baked in, each LDS word feeds ND*bs multiply-adds;
+//   * dot += v0*v1 stays a separate multiply and add (built with -ffp-contract=off):
+//     the parity anchor is the reference CPU build, which has no FMA.
+//
+// This kernel is VALU-bound by construction (3 non-fusable f32 ops per tap per output,
+// >= 243 ops per output for bs = 9); the HBM-roofline kernel is ncc_fast.hip.
+#include "ctd_common.h"
+
+namespace ctd {
+
+constexpr int kTW = 64;   // pixels per workgroup along w (one wavefront wide)
+constexpr int kTH = 4;    // pixel rows per workgroup
+constexpr int kND = 8;    // disparities register-blocked per thread
+
+// ---------------------------------------------------------------------------------
+// window statistics, reference order (ext.h:145-183): pass 1 mean with "x / T(bs^2)"
+// per tap, pass 2 sum of squared deviations.  One thread per (f, c, h, xi);
+// x = xi + x_start is the UNCLAMPED window centre column.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void window_stats_kernel(const T* __restrict__ in, long frame_stride, T* __restrict__ stats,
+                                    int C, int H, int W, int x_start, int W_out, int bs, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int xi = (int)(i % W_out);
+  long r = i / W_out;
+  int h = (int)(r % H);
+  r /= H;
+  int c = (int)(r % C);
+  int f = (int)(r / C);
+  const T* img = in + f * frame_stride + (long)c * H * W;
+  const int half = bs / 2;
+  const int x = xi + x_start;
+  const T bs2 = (T)(bs * bs);
+  T mu = 0;
+  for (int bh = 0; bh < bs; ++bh) {
+    int hh = clampi(h + bh - half, 0, H - 1);
+    for (int bw = 0; bw < bs; ++bw) {
+      int ww = clampi(x + bw - half, 0, W - 1);
+      mu += img[(long)hh * W + ww] / bs2;
+    }
+  }
+  T sigma = 0;
+  for (int bh = 0; bh < bs; ++bh) {
+    int hh = clampi(h + bh - half, 0, H - 1);
+    for (int bw = 0; bw < bs; ++bw) {
+      int ww = clampi(x + bw - half, 0, W - 1);
+      T v = img[(long)hh * W + ww] - mu;
+      sigma += v * v;
+    }
+  }
+  stats[2 * i] = mu;
+  stats[2 * i + 1] = sigma;
+}
+
+__device__ inline float ncc_norm(float s0, float s1) {
+  // T norm = sqrt(sigma0 * sigma1) + 1e-8;  sqrt in float, the add in double (ext.h:185)
+  return (float)((double)sqrtf(s0 * s1) + 1e-8);
+}
+__device__ inline double ncc_norm(double s0, double s1) { return sqrt(s0 * s1) + 1e-8; }
+
+// ---------------------------------------------------------------------------------
+// main kernel, f32, compile-time block size.
+//   grid  (ceil(W/kTW), ceil(H/kTH), frames), block (kTW, kTH)
+//   LDS   tile0 [(kTH+BS-1)][kTW+BS-1]           frame window, replicate border
+//         tile1 [(kTH+BS-1)][kTW+BS-1+Dpad-1]    pattern window for all disparities
+// ---------------------------------------------------------------------------------
+template <int BS, bool WRITE_VOL, bool ARGMAX, bool MULTI_C>
+__global__ __launch_bounds__(kTW* kTH, 3) void ncc_exact_kernel(
+    const float* __restrict__ in0, const float* __restrict__ in1, long in1_frame_stride,
+    const float2* __restrict__ stats0, const float2* __restrict__ stats1, float* __restrict__ out,
+    int64_t* __restrict__ idx_out, float* __restrict__ best_out, int C, int H, int W, int D) {
+  constexpr int HALF = BS / 2;
+  constexpr int TR = kTH + BS - 1;             // tile rows
+  constexpr int TW0 = kTW + BS - 1;
+  const int Dpad = (D + kND - 1) / kND * kND;
+  const int TW1 = kTW + BS - 1 + Dpad - 1;
+  const int W1 = W + Dpad - 1;                 // stats1 row: x = w - d in [-(Dpad-1), W-1]
+
+  extern __shared__ float smem[];
+  float* tile0 = smem;
+  float* tile1 = smem + TR * TW0;
+
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * kTW + tx;
+  const int w_lo = blockIdx.x * kTW, h_lo = blockIdx.y * kTH;
+  const int f = blockIdx.z;
+  const int w = w_lo + tx, h = h_lo + ty;
+  const bool active = (w < W) && (h < H);
+  const long HW = (long)H * W;
+  const float* img0 = in0 + (long)f * C * HW;
+  const float* img1 = in1 + (long)f * in1_frame_stride;
+  const float2* st0 = stats0 + (long)f * C * HW;
+  const float2* st1 = stats1 + (in1_frame_stride ? (long)f * C * H * W1 : 0);
+  float* vol = out + (long)f * D * HW;
+  const int x0_tile1 = w_lo - HALF - (Dpad - 1);
+
+  float bestv = 0.f;
+  int besti = 0;
+
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int i = tid; i < TR * TW0; i += kTW * kTH) {
+      int r = i / TW0, col = i - r * TW0;
+      int hh = clampi(h_lo + r - HALF, 0, H - 1);
+      int ww = clampi(w_lo + col - HALF, 0, W - 1);
+      tile0[i] = img0[(long)c * HW + (long)hh * W + ww];
+    }
+    for (int i = tid; i < TR * TW1; i += kTW * kTH) {
+      int r = i / TW1, col = i - r * TW1;
+      int hh = clampi(h_lo + r - HALF, 0, H - 1);
+      int ww = clampi(x0_tile1 + col, 0, W - 1);
+      tile1[i] = img1[(long)c * HW + (long)hh * W + ww];
+    }
+    __syncthreads();
+    if (!active) continue;
+
+    const float2 s0 = st0[(long)c * HW + (long)h * W + w];
+    float v0[BS * BS];
+#pragma unroll
+    for (int bh = 0; bh < BS; ++bh)
+#pragma unroll
+      for (int bw = 0; bw < BS; ++bw) v0[bh * BS + bw] = tile0[(ty + bh) * TW0 + tx + bw] - s0.x;
+
+    const float2* st1x = st1 + ((long)c * H + h) * W1 + (Dpad - 1) + w;   // st1x[-d] <-> x = w - d
+#pragma unroll 1
+    for (int d0 = 0; d0 < Dpad; d0 += kND) {
+      float acc[kND], mu1[kND];
+#pragma unroll
+      for (int j = 0; j < kND; ++j) {
+        mu1[j] = st1x[-d0 - j].x;
+        acc[j] = 0.f;
+      }
+      // The window of group d0+kND overlaps this group's by kND words; hide that from GVN's
+      // load-PRE, which would otherwise carry 9 x kND loaded words across the back edge in
+      // VGPRs (and spill the v0 taps to scratch to make room).
+      int col0 = Dpad - kND - d0;
+      asm volatile("" : "+s"(col0));
+      const float* rowp = tile1 + ty * TW1 + tx + col0;
+#pragma unroll
+      for (int bh = 0; bh < BS; ++bh) {
+        float br[kND + BS - 1];
+#pragma unroll
+        for (int k = 0; k < kND + BS - 1; ++k) br[k] = rowp[bh * TW1 + k];
+#pragma unroll
+        for (int j = 0; j < kND; ++j)
+#pragma unroll
+          for (int bw = 0; bw < BS; ++bw) {
+            float v1 = br[bw + kND - 1 - j] - mu1[j];
+            float p = v0[bh * BS + bw] * v1;   // separate multiply ...
+            acc[j] = acc[j] + p;               // ... and add: no FMA (ext.h:179 on the CPU build)
+          }
+        // keep the scheduler from hoisting the next rows' LDS reads over this row's
+        // 216 VALU ops (it otherwise runs the kernel out of VGPRs and spills)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // pin the sums here: LLVM otherwise sinks each acc[j] chain into its "d < D" block
+      // below, which keeps all 9 x (kND+BS-1) window words live and spills.
+#pragma unroll
+      for (int j = 0; j < kND; ++j) asm volatile("" : "+v"(acc[j]));
+#pragma unroll
+      for (int j = 0; j < kND; ++j) {
+        const int d = d0 + j;
+        float q = acc[j] / ncc_norm(s0.y, st1x[-d].y);
+        long o = (long)(d < D ? d : D - 1) * HW + (long)h * W + w;
+        float val = 0.f;
+        if (MULTI_C) val = (c == 0) ? 0.f : vol[o];   // channels accumulate in order c = 0..C-1
+        val += q;                                     // "T val = 0; val += dot / norm" (ext.h:142,186)
+        if (d < D) {
+          if (WRITE_VOL) vol[o] = val;
+          if (ARGMAX) {                               // only instantiated for C == 1
+            if (d == 0 || val > bestv) { bestv = val; besti = d; }
+          }
+        }
+      }
+    }
+  }
+  if (ARGMAX && active) {
+    long p = (long)f * HW + (long)h * W + w;
+    idx_out[p] = besti;
+    if (best_out) best_out[p] = bestv;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// generic fallback: any block size, f32 or f64, one thread per output exactly like the
+// reference functor (two passes over the window straight from global memory).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void ncc_direct_kernel(const T* __restrict__ in0, const T* __restrict__ in1, long in1_frame_stride,
+                                  T* __restrict__ out, int C, int H, int W, int D, int bs, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long HW = (long)H * W;
+  int w = (int)(i % W);
+  int h = (int)((i / W) % H);
+  int d = (int)((i / HW) % D);
+  int f = (int)(i / (HW * D));
+  const T* a = in0 + (long)f * C * HW;
+  const T* b = in1 + (long)f * in1_frame_stride;
+  const int half = bs / 2;
+  const T bs2 = (T)(bs * bs);
+  T val = 0;
+  for (int c = 0; c < C; ++c) {
+    T mu0 = 0, mu1 = 0;
+    for (int bh = 0; bh < bs; ++bh) {
+      int hh = clampi(h + bh - half, 0, H - 1);
+      for (int bw = 0; bw < bs; ++bw) {
+        int w0 = w + bw - half;
+        int w1 = clampi(w0 - d, 0, W - 1);
+        w0 = clampi(w0, 0, W - 1);
+        mu0 += a[(long)c * HW + (long)hh * W + w0] / bs2;
+        mu1 += b[(long)c * HW + (long)hh * W + w1] / bs2;
+      }
+    }
+    T s0 = 0, s1 = 0, dot = 0;
+    for (int bh = 0; bh < bs; ++bh) {
+      int hh = clampi(h + bh - half, 0, H - 1);
+      for (int bw = 0; bw < bs; ++bw) {
+        int w0 = w + bw - half;
+        int w1 = clampi(w0 - d, 0, W - 1);
+        w0 = clampi(w0, 0, W - 1);
+        T v0 = a[(long)c * HW + (long)hh * W + w0] - mu0;
+        T v1 = b[(long)c * HW + (long)hh * W + w1] - mu1;
+        dot += v0 * v1;
+        s0 += v0 * v0;
+        s1 += v1 * v1;
+      }
+    }
+    val += dot / ncc_norm(s0, s1);
+  }
+  out[i] = val;
+}
+
+// argmax over d of a materialised volume; first index wins (strict >), one thread per pixel.
+__global__ void argmax_disp_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
+                                   float* __restrict__ best, int D, long HW, long total) {
+  long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  long f = p / HW, q = p - f * HW;
+  const float* v = vol + f * D * HW + q;
+  float m = v[0];
+  int mi = 0;
+  int d = 1;
+  for (; d + 8 <= D; d += 8) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = v[(long)(d + k) * HW];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (t[k] > m) { m = t[k]; mi = d + k; }
+  }
+  for (; d < D; ++d) {
+    float t = v[(long)d * HW];
+    if (t > m) { m = t; mi = d; }
+  }
+  idx[p] = mi;
+  if (best) best[p] = m;
+}
+
+struct ExactWorkspace {
+  float2* stats0;
+  float2* stats1;
+  size_t bytes;
+};
+
+static ExactWorkspace exact_workspace(void* base, int frames, int C, int H, int W, int D, bool per_frame_pattern) {
+  const int W1 = W + (D + kND - 1) / kND * kND - 1;
+  size_t n0 = (size_t)frames * C * H * W * sizeof(float2);
+  size_t n1 = (size_t)(per_frame_pattern ? frames : 1) * C * H * W1 * sizeof(float2);
+  ExactWorkspace ws;
+  ws.stats0 = (float2*)base;
+  ws.stats1 = (float2*)((char*)base + align_up(n0, 256));
+  ws.bytes = align_up(n0, 256) + align_up(n1, 256);
+  return ws;
+}
+
+template <int BS, bool WRITE_VOL, bool ARGMAX, bool MULTI_C>
+static int launch_exact_c(const float* in0, const float* in1, long in1_frame_stride, float* out, int64_t* idx,
+                        float* best, int frames, int C, int H, int W, int D, void* workspace, hipStream_t stream) {
+  const bool per_frame = in1_frame_stride != 0;
+  ExactWorkspace ws = exact_workspace(workspace, frames, C, H, W, D, per_frame);
+  const int Dpad = (D + kND - 1) / kND * kND;
+  const int W1 = W + Dpad - 1;
+  {
+    long total = (long)frames * C * H * W;
+    hipLaunchKernelGGL(window_stats_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0,
+                       (long)C * H * W, (float*)ws.stats0, C, H, W, 0, W, BS, total);
+    CTD_LAUNCH_CHECK();
+    int nf1 = per_frame ? frames : 1;
+    total = (long)nf1 * C * H * W1;
+    hipLaunchKernelGGL(window_stats_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in1,
+                       in1_frame_stride, (float*)ws.stats1, C, H, W, -(Dpad - 1), W1, BS, total);
+    CTD_LAUNCH_CHECK();
+  }
+  const int TR = kTH + BS - 1;
+  size_t lds = sizeof(float) * (size_t)TR * ((kTW + BS - 1) + (kTW + BS - 1 + Dpad - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), frames), block(kTW, kTH);
+  auto kern = ncc_exact_kernel<BS, WRITE_VOL, ARGMAX, MULTI_C>;
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, in0, in1, in1_frame_stride, ws.stats0, ws.stats1, out, idx, best,
+                     C, H, W, D);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+template <int BS, bool WRITE_VOL, bool ARGMAX>
+static int launch_exact(const float* in0, const float* in1, long s1, float* out, int64_t* idx, float* best, int frames,
+                        int C, int H, int W, int D, void* ws, hipStream_t st) {
+  if (C == 1) return launch_exact_c<BS, WRITE_VOL, ARGMAX, false>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+  if (ARGMAX) return CTD_ERR_UNSUPPORTED;
+  return launch_exact_c<BS, WRITE_VOL, false, true>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+}
+
+template <bool WRITE_VOL, bool ARGMAX>
+static int dispatch_exact(int bs, const float* in0, const float* in1, long s1, float* out, int64_t* idx, float* best,
+                          int frames, int C, int H, int W, int D, void* ws, hipStream_t st) {
+  switch (bs) {
+    case 3: return launch_exact<3, WRITE_VOL, ARGMAX>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+    case 5: return launch_exact<5, WRITE_VOL, ARGMAX>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+    case 7: return launch_exact<7, WRITE_VOL, ARGMAX>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+    case 9: return launch_exact<9, WRITE_VOL, ARGMAX>(in0, in1, s1, out, idx, best, frames, C, H, W, D, ws, st);
+    default: return CTD_ERR_UNSUPPORTED;
+  }
+}
+
+static bool exact_has_tiled(int bs) { return bs == 3 || bs == 5 || bs == 7 || bs == 9; }
+
+// entry points used by ctd_api.hip -------------------------------------------------
+size_t ncc_exact_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern) {
+  if (!exact_has_tiled(bs)) return 256;
+  return exact_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
+}
+
+int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
+                  int W, int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (exact_has_tiled(bs)) {
+    if (workspace == nullptr || workspace_bytes < ncc_exact_workspace_bytes(frames, C, H, W, D, bs, in1_frame_stride != 0))
+      return CTD_ERR_WORKSPACE;
+    return dispatch_exact<true, false>(bs, in0, in1, in1_frame_stride, out, nullptr, nullptr, frames, C, H, W, D,
+                                       workspace, stream);
+  }
+  long total = (long)frames * D * H * W;
+  hipLaunchKernelGGL(ncc_direct_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0, in1,
+                     in1_frame_stride, out, C, H, W, D, bs, total);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int ncc_exact_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C, int H,
+                  int W, int D, int bs, hipStream_t stream) {
+  long total = (long)frames * D * H * W;
+  hipLaunchKernelGGL(ncc_direct_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0, in1,
+                     in1_frame_stride, out, C, H, W, D, bs, total);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
+                         float* best, int frames, int H, int W, int D, int bs, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+  if (!exact_has_tiled(bs)) return CTD_ERR_UNSUPPORTED;
+  if (workspace == nullptr || workspace_bytes < ncc_exact_workspace_bytes(frames, 1, H, W, D, bs, in1_frame_stride != 0))
+    return CTD_ERR_WORKSPACE;
+  if (vol_out)
+    return dispatch_exact<true, true>(bs, in0, in1, in1_frame_stride, vol_out, idx, best, frames, 1, H, W, D,
+                                      workspace, stream);
+  return dispatch_exact<false, true>(bs, in0, in1, in1_frame_stride, nullptr, idx, best, frames, 1, H, W, D, workspace,
+                                     stream);
+}
+
+int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream) {
+  long HW = (long)H * W, total = (long)frames * HW;
+  hipLaunchKernelGGL(argmax_disp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, vol, idx, best, D,
+                     HW, total);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+}  // namespace ctd

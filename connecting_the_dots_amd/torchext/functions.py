@@ -1,0 +1,161 @@
+"""Mirror of the reference's `torchext/functions.py` on top of libctd_hip.so.
+
+Same names, argument meaning, autograd contract and error behaviour as the reference
+(torchext/functions.py:1-147); every op takes CUDA(=HIP) tensors that are contiguous and
+launches on the caller's current stream and the tensor's device.  There is no CPU path in
+this package: CPU tensors raise (the reference's CPU path is `ext_cpu`, which lives on as
+the test oracle only).
+
+Additive API (no reference counterpart): `xcorrvol_batch`, `argmax_disp`,
+`xcorrvol_argmax`.
+"""
+import os
+
+import torch
+
+from .. import _lib
+
+_ALGOS = {"exact": 0, "fast": 1}
+
+
+def _default_algo():
+    return os.environ.get("CTD_NCC_ALGO", "exact")
+
+
+def _check(t, name, dtypes=(torch.float32, torch.float64)):
+    # CHECK_CUDA / CHECK_CONTIGUOUS of the reference binding (ext.h:6-10) -> RuntimeError
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor (connecting_the_dots_amd has no CPU path)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype not in dtypes:
+        raise RuntimeError("%s: unsupported dtype %s" % (name, t.dtype))
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _workspace(nbytes, dev):
+    # torch's caching allocator makes this a stream-ordered sub-allocation, no hipMalloc
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+# --------------------------------------------------------------------------------------
+# NCC volume (reference: XCorrVolFunction, functions.py:59-74)
+# --------------------------------------------------------------------------------------
+def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):
+    """in0 [N,C,H,W], in1 [C,H,W] | [N,C,H,W] -> [N,D,H,W]"""
+    L = _lib.lib()
+    dev = _same_device(in0, in1)
+    if in0.dtype != in1.dtype:
+        raise RuntimeError("in0 and in1 must have the same dtype")
+    N, C, H, W = in0.shape
+    if tuple(in1.shape[-3:]) != (C, H, W):
+        raise RuntimeError("in0 and in1 must have the same [C,H,W] shape")
+    stride1 = 0 if in1.dim() == 3 else C * H * W
+    if in1.dim() == 4 and in1.shape[0] != N:
+        raise RuntimeError("in1 batch does not match in0")
+    D, bs = int(n_disps), int(block_size)
+    out = torch.empty((N, D, H, W), dtype=in0.dtype, device=dev)
+    a = _ALGOS[algo]
+    ws_bytes = L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a)
+    ws = _workspace(ws_bytes, dev)
+    if in0.dtype == torch.float32:
+        st = L.ctd_xcorrvol_f32(_ptr(in0), _ptr(in1), stride1, _ptr(out), N, C, H, W, D, bs, a, _ptr(ws),
+                                ws.numel(), dev.index, _stream(dev))
+    else:
+        st = L.ctd_xcorrvol_f64(_ptr(in0), _ptr(in1), stride1, _ptr(out), N, C, H, W, D, bs, _ptr(ws), ws.numel(),
+                                dev.index, _stream(dev))
+    _lib.check(st, "xcorrvol")
+    return out
+
+
+class XCorrVolFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in0, in1, n_disps, block_size):
+        _check(in0, "in0")
+        _check(in1, "in1")
+        if in0.dim() != 3 or in1.dim() != 3:
+            raise RuntimeError("xcorrvol expects [C,H,W] tensors")
+        return _xcorrvol_impl(in0.unsqueeze(0), in1, n_disps, block_size, _default_algo())[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None, None, None
+
+
+def xcorrvol(in0, in1, n_disps, block_size):
+    """Zero-mean NCC volume [D,H,W] between in0 [C,H,W] at (h,w) and in1 at (h,w-d)."""
+    return XCorrVolFunction.apply(in0, in1, n_disps, block_size)
+
+
+def xcorrvol_batch(in0, in1, n_disps, block_size, algo=None):
+    """Additive: xcorrvol for a batch of frames in one launch.
+    in0 [N,C,H,W]; in1 [C,H,W] (shared pattern) or [N,C,H,W] -> [N,D,H,W]."""
+    _check(in0, "in0")
+    _check(in1, "in1")
+    if in0.dim() != 4 or in1.dim() not in (3, 4):
+        raise RuntimeError("xcorrvol_batch expects in0 [N,C,H,W] and in1 [C,H,W] or [N,C,H,W]")
+    return _xcorrvol_impl(in0, in1, n_disps, block_size, algo or _default_algo())
+
+
+def argmax_disp(vol):
+    """Additive: (torch.argmax(vol, -3), vol.max(-3)) for vol [D,H,W] or [N,D,H,W]; first index wins ties."""
+    _check(vol, "vol", (torch.float32,))
+    squeeze = vol.dim() == 3
+    v = vol.unsqueeze(0) if squeeze else vol
+    if v.dim() != 4:
+        raise RuntimeError("argmax_disp expects [D,H,W] or [N,D,H,W]")
+    N, D, H, W = v.shape
+    dev = v.device
+    idx = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+    best = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    st = _lib.lib().ctd_argmax_disp_f32(_ptr(v), _ptr(idx), _ptr(best), N, D, H, W, dev.index, _stream(dev))
+    _lib.check(st, "argmax_disp")
+    return (idx[0], best[0]) if squeeze else (idx, best)
+
+
+def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=None, rerank_eps=1e-5):
+    """Additive: fused NCC volume + argmax over disparity (C == 1).
+    in0 [N,1,H,W] | [1,H,W]; in1 [1,H,W] | [N,1,H,W].
+    Returns (idx int64, best f32[, volume]); idx == torch.argmax(xcorrvol(...), 0) of the reference."""
+    _check(in0, "in0", (torch.float32,))
+    _check(in1, "in1", (torch.float32,))
+    squeeze = in0.dim() == 3
+    a0 = in0.unsqueeze(0) if squeeze else in0
+    if a0.dim() != 4 or in1.dim() not in (3, 4):
+        raise RuntimeError("xcorrvol_argmax expects in0 [N,1,H,W] or [1,H,W]")
+    L = _lib.lib()
+    dev = _same_device(a0, in1)
+    N, C, H, W = a0.shape
+    if tuple(in1.shape[-3:]) != (C, H, W):
+        raise RuntimeError("in0 and in1 must have the same [C,H,W] shape")
+    stride1 = 0 if in1.dim() == 3 else C * H * W
+    D, bs = int(n_disps), int(block_size)
+    a = _ALGOS[algo or _default_algo()]
+    idx = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+    best = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if return_volume else None
+    ws = _workspace(L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a), dev)
+    st = L.ctd_xcorrvol_argmax_f32(_ptr(a0), _ptr(in1), stride1, _ptr(vol), _ptr(idx), _ptr(best), N, C, H, W, D, bs,
+                                   a, float(rerank_eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(st, "xcorrvol_argmax")
+    if squeeze:
+        idx, best = idx[0], best[0]
+        vol = vol[0] if vol is not None else None
+    return (idx, best, vol) if return_volume else (idx, best)

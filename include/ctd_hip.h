@@ -1,0 +1,101 @@
+/*
+ * ctd_hip.h -- C ABI of libctd_hip.so, the MI355X (gfx950) implementation of the
+ * disparity hot path of autonomousvision/connecting_the_dots.
+ *
+ * This is the drop-in boundary: each entry point replaces one pybind11 function of
+ * the reference's CUDA extension (torchext/ext/ext_cuda.cpp:126-135) or fuses a chain
+ * of stock PyTorch ops of model/networks.py.  Signatures carry plain device pointers,
+ * sizes, a device ordinal and a hipStream_t (as void*); no torch / pybind types.
+ *
+ * Conventions
+ *   - all tensors are dense, row-major, already resident in device memory;
+ *   - the callee never allocates, frees or synchronises: outputs and workspaces are
+ *     provided by the caller (the reference allocated outputs with ATen inside the
+ *     call, ext_cuda.cpp:81,100,119; here the Python wrapper does it with torch.empty);
+ *   - `device` is the HIP device ordinal the pointers live on (-1 = current device);
+ *     `stream` is the hipStream_t to launch on (NULL = default stream).  The reference
+ *     launched on the legacy default stream with no device guard (common_cuda.h:168);
+ *   - return value: 0 on success, otherwise a ctd_status code (never exit(), unlike
+ *     common_cuda.h:11-20); ctd_status_string() names it;
+ *   - kernels are deterministic: no floating-point atomics anywhere.
+ */
+#ifndef CTD_HIP_H
+#define CTD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum ctd_status {
+  CTD_OK = 0,
+  CTD_ERR_INVALID_ARG = 1,     /* bad size / null pointer / unsupported parameter        */
+  CTD_ERR_WORKSPACE = 2,       /* workspace too small                                     */
+  CTD_ERR_UNSUPPORTED = 3,     /* valid request this build has no kernel for              */
+  CTD_ERR_HIP = 1000           /* 1000 + hipError_t of the failing runtime call           */
+};
+
+int ctd_version(void);                       /* ABI version, currently 1 */
+const char* ctd_status_string(int status);
+
+/* photometric loss types -- torchext/ext/ext.h:196-199, torchext/functions.py:106-118 */
+#define CTD_PHOTOMETRIC_MSE 0
+#define CTD_PHOTOMETRIC_SAD 1
+#define CTD_PHOTOMETRIC_CENSUS_MSE 2
+#define CTD_PHOTOMETRIC_CENSUS_SAD 3
+
+/* algorithm selector of the NCC volume */
+#define CTD_NCC_EXACT 0   /* reference operation order, bit-identical to ext_cpu.cpp        */
+#define CTD_NCC_FAST 1    /* separable window sums; |a-b| <= 1e-5|b| + 1e-6 of the exact   */
+
+/* --------------------------------------------------------------------------------------
+ * Zero-mean NCC block-matching volume.
+ * Replaces  xcorrvol_cuda(in0, in1, n_disps, block_size)  -- ext_cuda.cpp:73-86,
+ * kernel ext_kernel.cu:40-50, functor ext.h:120-191.
+ *
+ *   in0  [frames][C][H][W]   IR frames
+ *   in1  [C][H][W]           pattern, shared by all frames when in1_frame_stride == 0,
+ *                            else in1 + f*in1_frame_stride (elements) is frame f's pattern
+ *   out  [frames][D][H][W]
+ * The reference op has no batch axis (functions.py:73-74 is called per frame);
+ * frames == 1 reproduces it exactly, frames > 1 is the same op applied per frame in
+ * one launch.  `algo` = CTD_NCC_EXACT | CTD_NCC_FAST.
+ * Workspace: ctd_xcorrvol_workspace_bytes() bytes, 256-byte aligned, contents scratch.
+ * -------------------------------------------------------------------------------------- */
+size_t ctd_xcorrvol_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo);
+
+int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, float* out,
+                     int frames, int C, int H, int W, int D, int block_size, int algo,
+                     void* workspace, size_t workspace_bytes, int device, void* stream);
+
+int ctd_xcorrvol_f64(const double* in0, const double* in1, long in1_frame_stride, double* out,
+                     int frames, int C, int H, int W, int D, int block_size,
+                     void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * argmax over the disparity axis:  idx = torch.argmax(vol, dim=0)  (first index wins
+ * ties), best = vol.max(0).  No reference code.
+ *   vol [frames][D][H][W] -> idx int64 [frames][H][W], best f32 [frames][H][W] (may be NULL)
+ * -------------------------------------------------------------------------------------- */
+int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H,
+                        int W, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Fused NCC volume + argmax without materialising the volume (C == 1 only).
+ *   vol_out may be NULL (no volume written) or [frames][D][H][W] (written as well).
+ * With CTD_NCC_EXACT the indices equal torch.argmax(xcorrvol_cpu(...), 0) bit for bit.
+ * With CTD_NCC_FAST the fast volume is ranked and every disparity whose fast score lies
+ * within `rerank_eps` of the pixel's best is re-evaluated in reference order, so the
+ * indices are those of the exact volume whenever |fast - exact| <= rerank_eps / 2.
+ * -------------------------------------------------------------------------------------- */
+int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,
+                            float* vol_out, int64_t* idx, float* best, int frames, int C, int H,
+                            int W, int D, int block_size, int algo, float rerank_eps,
+                            void* workspace, size_t workspace_bytes, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTD_HIP_H */
