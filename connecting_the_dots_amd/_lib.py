@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libctd_hip.so")
+# CTD_HIP_LIB: alternative build of the same ABI (kernel experiments); default is the in-tree library
+LIB_PATH = os.environ.get("CTD_HIP_LIB") or os.path.join(_PKG, "libctd_hip.so")
 
 _c_int, _c_long, _c_float, _c_size_t, _vp = (ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t,
                                              ctypes.c_void_p)
@@ -21,6 +22,7 @@ SIGNATURES = {
     "ctd_argmax_disp_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_int, _vp]),
     "ctd_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 7 + [_c_float, _vp, _c_size_t,
                                                                                           _c_int, _vp]),
+    "ctd_lcn_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
 }
 
 _lib = None

@@ -31,8 +31,9 @@ size_t ctd_xcorrvol_workspace_bytes(int frames, int C, int H, int W, int D, int 
   if (!vol_shape_ok(frames, C, H, W, D, block_size)) return 0;
   // worst case over "pattern shared" / "pattern per frame"
   size_t exact = ncc_exact_workspace_bytes(frames, C, H, W, D, block_size, true);
-  (void)algo;
-  return exact;
+  if (algo == CTD_NCC_EXACT) return exact;
+  size_t fast = ncc_fast_workspace_bytes(frames, C, H, W, D, block_size, true);
+  return fast > exact ? fast : exact;
 }
 
 int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
@@ -46,7 +47,10 @@ int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, 
   if (algo == CTD_NCC_EXACT)
     return ncc_exact_f32(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
                          (hipStream_t)stream);
-  return CTD_ERR_UNSUPPORTED;
+  if (algo == CTD_NCC_FAST)
+    return ncc_fast_f32(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
+                        (hipStream_t)stream);
+  return CTD_ERR_INVALID_ARG;
 }
 
 int ctd_xcorrvol_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C,
@@ -86,6 +90,16 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
                                 workspace_bytes, (hipStream_t)stream);
   return CTD_ERR_UNSUPPORTED;
+}
+
+int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius, float eps, int device,
+                void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || radius < 0 || radius >= H || radius >= W) return CTD_ERR_INVALID_ARG;
+  if (N == 0) return CTD_OK;
+  if (!x || !y || !std_out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return lcn_f32(x, y, std_out, N, H, W, radius, eps, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -15,4 +15,12 @@ int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stri
                          size_t workspace_bytes, hipStream_t stream);
 int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream);
 
+// ncc_fast.hip
+size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
+int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
+                 int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+// lcn.hip
+int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
+
 }  // namespace ctd

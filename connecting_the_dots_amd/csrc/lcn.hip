@@ -1,0 +1,102 @@
+// lcn.hip -- fused local contrast normalisation.
+//
+// Replaces the op chain of LCN.tforward (model/networks.py:507-533): ReflectionPad2d,
+// two all-ones (2r+1)^2 Conv2d passes (x and x^2) and six elementwise kernels, each a
+// full HBM round trip in the reference.  Here one kernel reads x once (12 B/pixel of
+// algorithmic traffic: 4 in, 8 out) and produces both outputs.
+//
+// Numerics: the box sums are accumulated separably in f64 (dx ascending inside a row,
+// dy ascending across rows) and rounded once to f32, which is within half an ulp of the
+// exact sum -- ATen's conv2d summation order is unspecified, so this is the closest
+// defined target -- and the elementwise tail follows the reference's f32 operation order:
+//     avgs = boxs / n;  stds = sqrt(boxs2 / n - avgs*avgs + 1e-6) + eps;  y = (x - avgs) / stds
+// The CPU oracle (oracle/ctd_oracle.c: ctd_oracle_lcn_f32) uses the same order, so the
+// two agree bit for bit.
+#include "ctd_internal.h"
+
+namespace ctd {
+
+constexpr int kLcnTW = 64;
+constexpr int kLcnTH = 16;
+constexpr int kLcnRows = 4;   // block = 64 x 4 threads, each thread owns kLcnTH / 4 output rows
+
+__device__ inline int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i > n - 1) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               float* __restrict__ stds, int H, int W, int radius,
+                                                               float eps) {
+  extern __shared__ double lds_d[];
+  const int TRr = kLcnTH + 2 * radius;       // staged rows
+  const int TCc = kLcnTW + 2 * radius;       // staged columns
+  double* rs1 = lds_d;                       // [TRr][kLcnTW] row sums of x
+  double* rs2 = lds_d + TRr * kLcnTW;        // [TRr][kLcnTW] row sums of x^2
+  float* tile = (float*)(lds_d + 2 * TRr * kLcnTW);   // [TRr][TCc] reflect-padded input
+
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * kLcnTW + tx;
+  const int w_lo = blockIdx.x * kLcnTW, h_lo = blockIdx.y * kLcnTH;
+  const long base = (long)blockIdx.z * H * W;
+  const float* xb = x + base;
+
+  for (int i = tid; i < TRr * TCc; i += kLcnTW * kLcnRows) {
+    int r = i / TCc, c = i - r * TCc;
+    // tiles hanging over the bottom / right edge stage clamped garbage that is never stored
+    int hh = reflect_idx(min(h_lo + r - radius, H - 1 + radius), H);
+    int ww = reflect_idx(min(w_lo + c - radius, W - 1 + radius), W);
+    tile[i] = xb[(long)hh * W + ww];
+  }
+  __syncthreads();
+
+  for (int r = ty; r < TRr; r += kLcnRows) {
+    const float* row = tile + r * TCc + tx;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k <= 2 * radius; ++k) {
+      float v = row[k];
+      float v2 = v * v;                       // data**2 is an f32 tensor (networks.py:528)
+      s1 += (double)v;
+      s2 += (double)v2;
+    }
+    rs1[r * kLcnTW + tx] = s1;
+    rs2[r * kLcnTW + tx] = s2;
+  }
+  __syncthreads();
+
+  const int w = w_lo + tx;
+  const float cnt = (float)((2 * radius + 1) * (2 * radius + 1));
+  for (int r = ty; r < kLcnTH; r += kLcnRows) {
+    const int h = h_lo + r;
+    if (w >= W || h >= H) continue;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k <= 2 * radius; ++k) {
+      s1 += rs1[(r + k) * kLcnTW + tx];
+      s2 += rs2[(r + k) * kLcnTW + tx];
+    }
+    float boxs = (float)s1, boxs2 = (float)s2;
+    float avgs = boxs / cnt;
+    float var = boxs2 / cnt - avgs * avgs + 1e-6f;
+    float sd = sqrtf(var) + eps;
+    float xv = tile[(r + radius) * TCc + tx + radius];
+    long o = base + (long)h * W + w;
+    y[o] = (xv - avgs) / sd;
+    stds[o] = sd;
+  }
+}
+
+int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream) {
+  const int TRr = kLcnTH + 2 * radius, TCc = kLcnTW + 2 * radius;
+  size_t lds = sizeof(double) * 2 * TRr * kLcnTW + sizeof(float) * (size_t)TRr * TCc;
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  auto kern = lcn_kernel;
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid(ceil_div(W, kLcnTW), ceil_div(H, kLcnTH), N), block(kLcnTW, kLcnRows);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, x, y, stds, H, W, radius, eps);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+}  // namespace ctd

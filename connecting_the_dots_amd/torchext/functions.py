@@ -7,7 +7,7 @@ this package: CPU tensors raise (the reference's CPU path is `ext_cpu`, which li
 the test oracle only).
 
 Additive API (no reference counterpart): `xcorrvol_batch`, `argmax_disp`,
-`xcorrvol_argmax`.
+`xcorrvol_argmax`, `lcn`.
 """
 import os
 
@@ -159,3 +159,26 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
         idx, best = idx[0], best[0]
         vol = vol[0] if vol is not None else None
     return (idx, best, vol) if return_volume else (idx, best)
+
+
+# --------------------------------------------------------------------------------------
+# LCN (reference: networks.LCN.tforward, model/networks.py:523-533 -- not part of the
+# reference's torchext; exposed here so the whole pre-normalisation is one kernel)
+# --------------------------------------------------------------------------------------
+def lcn(data, radius, epsilon):
+    """data [N,1,H,W] f32 -> ((data - avg) / std, std), std = sqrt(E[x^2] - avg^2 + 1e-6) + epsilon,
+    box statistics over a (2*radius+1)^2 reflect-padded window.  Not differentiable (the reference
+    only ever applies it to input images, exp_synph.py:84-91)."""
+    _check(data, "data", (torch.float32,))
+    if data.dim() != 4 or data.shape[1] != 1:
+        raise RuntimeError("lcn expects [N,1,H,W]")
+    N, _, H, W = data.shape
+    if not (0 <= int(radius) < min(H, W)):
+        raise RuntimeError("lcn: radius must be smaller than the image (ReflectionPad2d rule)")
+    dev = data.device
+    y = torch.empty_like(data)
+    std = torch.empty_like(data)
+    st = _lib.lib().ctd_lcn_f32(_ptr(data), _ptr(y), _ptr(std), N, H, W, int(radius), float(epsilon), dev.index,
+                                _stream(dev))
+    _lib.check(st, "lcn")
+    return y, std

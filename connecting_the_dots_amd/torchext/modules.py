@@ -24,3 +24,16 @@ class CoordConv2d(torch.nn.Module):
         self.uv = self.uv.to(x.device)
         uv = self.uv.expand(x.shape[0], *self.uv.shape[1:])
         return self.conv(torch.cat((x, uv), dim=1))
+
+
+class LCN(torch.nn.Module):
+    """Local contrast normalisation with the constructor / call signature of the reference's
+    `networks.LCN(radius, epsilon)` (model/networks.py:507-533); one fused HIP kernel."""
+
+    def __init__(self, radius, epsilon):
+        super().__init__()
+        self.radius = radius
+        self.epsilon = epsilon
+
+    def forward(self, data):
+        return lcn(data.contiguous(), self.radius, self.epsilon)  # noqa: F405

@@ -95,6 +95,14 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
                             int W, int D, int block_size, int algo, float rerank_eps,
                             void* workspace, size_t workspace_bytes, int device, void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * Local contrast normalisation, fused.  Replaces the op chain of LCN.tforward,
+ * model/networks.py:507-533 (ReflectionPad2d + two all-ones Conv2d + 6 elementwise ops).
+ *   x [N][1][H][W] -> y = (x-avg)/std, std  (both [N][1][H][W]);  radius < min(H, W)
+ * -------------------------------------------------------------------------------------- */
+int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
+                float eps, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

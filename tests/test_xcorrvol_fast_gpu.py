@@ -1,0 +1,84 @@
+"""GPU parity of the separable-sum NCC volume (algo='fast'): float tolerance of SURVEY 8d,
+|a-b| <= 1e-5*|b| + 1e-6, against the reference-order oracle / goldens."""
+import numpy as np
+import pytest
+import torch
+
+from tests import workloads
+from tests.util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def te():
+    from connecting_the_dots_amd import torchext
+    return torchext
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_fast_small_goldens(te):
+    g = golden("xcorrvol_small")
+    n = 0
+    for k, (C, H, W, D, bs) in enumerate(g["cases"]):
+        if g["in0_%d" % k].dtype != np.float32 or bs % 2 == 0:
+            continue
+        n += 1
+        vol = te.xcorrvol_batch(dev(g["in0_%d" % k][None]), dev(g["in1_%d" % k]), int(D), int(bs), algo="fast")
+        assert_close(vol[0].cpu().numpy(), g["vol_%d" % k], what="case %d" % k)
+    assert n >= 4
+
+
+@pytest.mark.parametrize("shape", [(1, 7, 9, 5, 9), (2, 33, 130, 37, 9), (1, 5, 64, 128, 9), (1, 40, 200, 19, 7),
+                                   (1, 11, 70, 9, 5), (1, 11, 70, 9, 3), (1, 150, 57, 16, 9), (1, 8, 300, 256, 9)])
+@pytest.mark.parametrize("kind", ["normal", "uniform", "offset"])
+def test_fast_vs_oracle_ragged(te, oracle, shape, kind):
+    C, H, W, D, bs = shape
+    rs = np.random.RandomState(sum(shape))
+    if kind == "normal":
+        a, b = rs.randn(C, H, W), rs.randn(C, H, W)
+    elif kind == "uniform":
+        a, b = rs.rand(C, H, W), rs.rand(C, H, W)
+    else:                                   # 8-bit style intensities with a large DC offset
+        a, b = rs.rand(C, H, W) * 60 + 150, rs.rand(C, H, W) * 90 + 100
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    ref = oracle.xcorrvol(a, b, D, bs, nthreads=8)
+    vol = te.xcorrvol_batch(dev(a[None]), dev(b), D, bs, algo="fast")[0].cpu().numpy()
+    assert_close(vol, ref, what="%s %s" % (shape, kind))
+
+
+def test_fast_left_border_ties_stay_exact(te):
+    """Once w - d + 4 < 0 every pattern tap clamps to column 0 (ext.h:152-154): the reference volume is
+    exactly constant in d there; the fast kernel must keep those ties exact (first index wins later)."""
+    rs = np.random.RandomState(3)
+    a = rs.randn(1, 1, 20, 64).astype(np.float32)
+    b = rs.randn(1, 20, 64).astype(np.float32)
+    vol = te.xcorrvol_batch(dev(a), dev(b), 32, 9, algo="fast")[0].cpu().numpy()
+    for w in range(0, 20):
+        d0 = w + 4                                  # all d >= d0 see the same clamped window
+        if d0 + 1 < 32:
+            assert (vol[d0:, :, w] == vol[d0, :, w]).all(), w
+
+
+def test_fast_cfg1_full_size(te):
+    g = golden("xcorrvol_cfg1")
+    a = workloads.uniform_frame(1234, 432, 512)
+    b = workloads.uniform_frame(42, 432, 512)
+    vol = te.xcorrvol_batch(dev(a[None]), dev(b), 128, 9, algo="fast")[0]
+    got = vol.reshape(-1)[torch.from_numpy(g["sample_idx"]).cuda()].cpu().numpy()
+    assert_close(got, g["uni_sample_val"], what="cfg1 uniform samples")
+    # algorithm-independent property: NCC of a frame with itself is 1 at d = 0
+    self_vol = te.xcorrvol_batch(dev(a[None]), dev(a), 4, 9, algo="fast")[0, 0].cpu().numpy()
+    assert np.abs(self_vol - 1).max() < 1e-5
+
+
+def test_fast_multichannel_and_per_frame_pattern(te, oracle):
+    rs = np.random.RandomState(12)
+    a = rs.randn(2, 3, 24, 70).astype(np.float32)
+    b = rs.randn(2, 3, 24, 70).astype(np.float32)
+    vol = te.xcorrvol_batch(dev(a), dev(b), 20, 9, algo="fast").cpu().numpy()
+    for f in range(2):
+        assert_close(vol[f], oracle.xcorrvol(a[f], b[f], 20, 9, nthreads=4), rtol=1e-5, atol=3e-6, what="frame %d" % f)

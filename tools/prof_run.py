@@ -1,0 +1,12 @@
+"""Runs one hot-path kernel family a few times (profiling target for rocprofv3 --pmc passes)."""
+import sys, torch
+from connecting_the_dots_amd import torchext as te
+algo = sys.argv[1] if len(sys.argv) > 1 else "fast"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+H, W, D = 432, 512, 128
+torch.manual_seed(0)
+a = torch.rand(N, 1, H, W, device="cuda"); b = torch.rand(1, 1, H, W, device="cuda")
+a, _ = te.lcn(a, 5, 0.05); b, _ = te.lcn(b, 5, 0.05); b = b[0].contiguous()
+for _ in range(3):
+    v = te.xcorrvol_batch(a, b, D, 9, algo=algo)
+torch.cuda.synchronize()
