@@ -18,7 +18,7 @@ HEADER = os.path.join(os.path.dirname(PKG), "include", "ctd_hip.h")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

@@ -21,9 +21,12 @@
 //     (no running sums, so no drift: every output is a fresh <= 4-level sum);
 //   * horizontal bs-sum across lanes: +-1 with DPP wave shifts, +-3 with ds_bpermute;
 //     64-(bs-1) of the 64 lanes produce outputs, stored as one contiguous row segment;
-//   * a', b' are centred by per-block constants (exact-arithmetic no-op, removes the
-//     cancellation in S_ab - n*ma*mb for inputs with a DC offset).
-// Window means / deviations (ma, sa, mb, sb) come from a separable f64 pre-pass.
+//   * a', b' are the inputs minus one constant per image (the window mean at the image
+//     centre): an exact-arithmetic no-op for NCC that removes the cancellation in
+//     S_ab - n*ma*mb for inputs with a DC offset.  The pre-pass writes the centred copies,
+//     so the main kernels never subtract; one constant per image also keeps the
+//     reference's exact ties along d at the left border exact (same operands, same order).
+// Window means / deviations (ma, sa, mb, sb) come from the same separable f64 pre-pass.
 #include "ctd_internal.h"
 
 #ifndef CTD_ABLATE
@@ -48,10 +51,16 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // ------------------------------------------------------------------------------------
 constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
 
-__global__ __launch_bounds__(kSTW* kSRows) void ncc_window_stats_kernel(const float* __restrict__ in,
-                                                                       long frame_stride, float* __restrict__ stats_mean, float* __restrict__ stats_dev,
-                                                                       int H, int W, int x_start, int W_out, int bs) {
+// out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
+// (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
+// cval = f64 window mean at the image centre, recomputed identically by every workgroup.
+__global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* __restrict__ in, long frame_stride,
+                                                                  float* __restrict__ out_img,
+                                                                  float* __restrict__ out_mean,
+                                                                  float* __restrict__ out_dev, int H, int W,
+                                                                  int x_start, int W_out, int bs) {
   extern __shared__ double lds_d[];
+  __shared__ double cred[kSTW * kSRows];
   const int half = bs / 2;
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   double* rs1 = lds_d;
@@ -60,6 +69,14 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_window_stats_kernel(const fl
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kSTW + tx;
   const int xi_lo = blockIdx.x * kSTW, h_lo = blockIdx.y * kSTH;
   const float* img = in + (long)blockIdx.z * frame_stride;      // z = frame * C + channel
+  {
+    double t = 0;
+    for (int k = tid; k < bs * bs; k += kSTW * kSRows) {
+      int hh = clampi(H / 2 + k / bs - half, 0, H - 1), ww = clampi(W / 2 + k % bs - half, 0, W - 1);
+      t += (double)img[(long)hh * W + ww];
+    }
+    cred[tid] = t;
+  }
   for (int i = tid; i < TRr * TCc; i += kSTW * kSRows) {
     int r = i / TCc, c = i - r * TCc;
     int hh = clampi(h_lo + r - half, 0, H - 1);
@@ -67,6 +84,12 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_window_stats_kernel(const fl
     tile[i] = img[(long)hh * W + ww];
   }
   __syncthreads();
+  for (int stride = kSTW * kSRows / 2; stride > 0; stride >>= 1) {   // fixed tree: same bits in every workgroup
+    if (tid < stride) cred[tid] += cred[tid + stride];
+    __syncthreads();
+  }
+  const double n = (double)(bs * bs);
+  const float cval = (float)(cred[0] / n);
   for (int r = ty; r < TRr; r += kSRows) {
     const float* row = tile + r * TCc + tx;
     double s1 = 0, s2 = 0;
@@ -80,7 +103,6 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_window_stats_kernel(const fl
   }
   __syncthreads();
   const int xi = xi_lo + tx;
-  const double n = (double)(bs * bs);
   for (int r = ty; r < kSTH; r += kSRows) {
     const int h = h_lo + r;
     if (xi >= W_out || h >= H) continue;
@@ -92,8 +114,9 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_window_stats_kernel(const fl
     double mean = s1 / n;
     double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
     const long o = ((long)blockIdx.z * H + h) * W_out + xi;
-    stats_mean[o] = (float)mean;
-    stats_dev[o] = (float)sqrt(var > 0 ? var : 0.0);
+    out_mean[o] = (float)(mean - (double)cval);
+    out_dev[o] = (float)sqrt(var > 0 ? var : 0.0);
+    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
   }
 }
 
@@ -157,10 +180,10 @@ __device__ inline void wg_barrier() {
 
 template <int BS, bool ACCUM>
 __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
-    const float* __restrict__ in0, const float* __restrict__ in1, long in1_frame_stride,
-    const float* __restrict__ m0, const float* __restrict__ v0, const float* __restrict__ m1,
-    const float* __restrict__ v1, long st1_frame_stride, float* __restrict__ out, int C, int c, int H, int W, int D,
-    int band_rows, int n_dgroups, int W1, int xoff) {
+    const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
+    const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int W1, int xoff,
+    int w_start) {
   constexpr int HALF = BS / 2;
   constexpr int TAIL = BS - 1 - HALF;          // window rows/cols after the centre
   constexpr int WOUT = 64 - (BS - 1);          // output columns per wavefront
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
-  const int w_lo = blockIdx.x * WOUT;
+  const int w_lo = w_start + blockIdx.x * WOUT;
   const int h_lo = blockIdx.y * band_rows;
   const int h_hi = min(h_lo + band_rows, H);   // exclusive
   const long HW = (long)H * W;
@@ -179,8 +202,8 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
   const int n_iters = (n_rows + STEP - 1) / STEP;
   const int n_chunks = n_iters * (STEP / kFRows);
 
-  const float* a_img = in0 + ((long)f * C + c) * HW;
-  const float* b_img = in1 + (long)f * in1_frame_stride + (long)c * HW;
+  const float* a_img = ac + ((long)f * C + c) * HW;
+  const float* b_img = bc + (long)f * st1_frame_stride + (long)c * H * W1;
   const float* m0i = m0 + ((long)f * C + c) * HW;
   const float* v0i = v0 + ((long)f * C + c) * HW;
   const float* m1i = m1 + (long)f * st1_frame_stride + (long)c * H * W1;
@@ -191,7 +214,6 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
     // ------------------------------ loader wavefront ------------------------------
     const int wa = clampi(w_lo - HALF + lane, 0, W - 1);
     const int q1 = 64 + lane;                                 // second DMA of a span: slots 64..78
-    const int bc0 = clampi(xb + lane, 0, W - 1), bc1 = clampi(xb + q1, 0, W - 1);
     const int sc0 = clampi(xb + lane, -xoff, W - 1) + xoff, sc1 = clampi(xb + q1, -xoff, W - 1) + xoff;
     const bool second = q1 < kFSpan;
     auto issue_chunk = [&](int chunk) {
@@ -205,14 +227,14 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
         dma_dword(a_img + (long)rc * W + wa, pk);
         dma_dword(m0i + (long)hs * W + wa, pk + 64);
         dma_dword(v0i + (long)hs * W + wa, pk + 128);
-        dma_dword(b_img + (long)rc * W + bc0, pk + 192);
+        dma_dword(b_img + (long)rc * W1 + sc0, pk + 192);
         dma_dword(m1i + (long)hs * W1 + sc0, pk + 192 + kFSpanPad);
         dma_dword(v1i + (long)hs * W1 + sc0, pk + 192 + 2 * kFSpanPad);
         // lanes >= 15 re-fetch slot 78's column into the pad slot / next array's head;
         // harmless: the pad is never read and the next array is rewritten by ITS OWN DMA
         // only if issued later -- so issue the tails BEFORE nothing depends on order:
         if (second) {
-          dma_dword(b_img + (long)rc * W + bc1, pk + 192 + 64);
+          dma_dword(b_img + (long)rc * W1 + sc1, pk + 192 + 64);
           dma_dword(m1i + (long)hs * W1 + sc1, pk + 192 + kFSpanPad + 64);
           dma_dword(v1i + (long)hs * W1 + sc1, pk + 192 + 2 * kFSpanPad + 64);
         }
@@ -243,13 +265,6 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
   const int d_base = dg * kFDG + wave * kFND;
   const int w0 = w_lo - HALF + lane;           // unclamped product column == output column
   float* vol = out + (long)f * D * HW;
-  float cb[kFND];
-  const int hc = (h_lo + h_hi) >> 1;
-  const int wc = min(w_lo + WOUT / 2, W - 1);
-  const float ca = m0i[(long)hc * W + wc];
-#pragma unroll
-  for (int j = 0; j < kFND; ++j)
-    cb[j] = m1i[(long)hc * W1 + clampi(wc - (d_base + j), -xoff, W - 1) + xoff];
   const bool lane_out = (lane >= HALF) && (lane < 64 - TAIL) && (w0 < W);
   const float nf = (float)(BS * BS);
   const int bq = lane + (kFDG - 1) - wave * kFND;   // span slot of (lane, j = 0); j-th disparity reads bq - j
@@ -264,9 +279,6 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
     for (int k = 0; k < (BS == 9 ? 6 : 1); ++k) T[j][k] = 0.f;
   }
 
-  // the centring constants above are the only global loads of a consumer; drain them
-  // here so that no later wait ever has to cover a load again
-  wait_vmcnt<0>();
   wg_barrier();                                                    // chunk 0 is in LDS
   int chunk = 0;
   for (int it = 0; it < n_iters; ++it) {
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
     for (int u = 0; u < STEP; ++u) {
       const int r = r_begin + it * STEP + u;
       const float* pk = lds + ((chunk % kFBufs) * kFRows + (u % kFRows)) * kFPack;
-      const float a = pk[lane] - ca;
+      const float a = pk[lane];
       const float mav = pk[64 + lane], sav = pk[128 + lane];
       float bv[kFND], mbv[kFND], sbv[kFND];
 #pragma unroll
@@ -285,11 +297,10 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
       }
       const int h = r - TAIL;                                     // output row completed by product row r
       const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
-      const float nma = -nf * (mav - ca);
+      const float nma = -nf * mav;
 #pragma unroll
       for (int j = 0; j < kFND; ++j) {
-        const float b = bv[j] - cb[j];
-        const float p = a * b;
+        const float p = a * bv[j];
         float v;
         if constexpr (BS == 9) {
           const float t3 = p + P[j][(u + 1) % 2] + P[j][u % 2];
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
 #else
         const float s = lane_window_sum<BS>(v, lane);
 #endif
-        const float cov = fmaf(nma, mbv[j] - cb[j], s);
+        const float cov = fmaf(nma, mbv[j], s);
         const float den = fmaf(sav, sbv[j], 1e-8f);
         float val = cov * __builtin_amdgcn_rcpf(den);
         const int d = d_base + j;
@@ -330,8 +341,327 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// WIDE kernel: every lane owns 4 adjacent product columns, a wavefront 256 of them.
+// A bs <= 9 window then reaches only into the two neighbouring lanes, so the horizontal
+// window sum needs nothing but +-1 lane DPP shifts of per-lane prefix / suffix sums
+// (no LDS crossbar traffic), 62 of 64 lanes produce outputs, frame-side LDS reads are
+// one ds_read_b128 per array and each lane stores 16 contiguous bytes (1 KB per wave
+// instruction).  Same loader / consumer split and LDS ring as the narrow kernel above,
+// which remains in use for the columns left over when W is not a multiple of 248.
+// ------------------------------------------------------------------------------------
+constexpr int kWCols = 4;                     // product columns per lane
+constexpr int kWND = 2;                       // disparities per lane
+constexpr int kWWaves = 4;                    // consumer wavefronts per workgroup
+constexpr int kWDG = kWND * kWWaves;          // disparities per workgroup (8)
+constexpr int kWTile = 64 * kWCols;           // product columns per wavefront (256)
+constexpr int kWOut = 62 * kWCols;            // output columns per wavefront (248)
+constexpr int kWSpan = kWTile + kWDG - 1;     // 263 pattern columns per row
+constexpr int kWSpanPad = 264;
+constexpr int kWPack = 3 * kWTile + 3 * kWSpanPad;   // 1560 floats per staged row
+constexpr int kWRows = 2;                     // rows per LDS chunk
+constexpr int kWBufs = 3;                     // chunks in the ring
+constexpr int kWDmaPerRow = 3 * 4 + 3 * 5;    // 27 dword LDS-DMA instructions per row
+
+// Four floats starting OFF slots after the lane's own quad of a 16-byte aligned LDS array:
+// one or two conflict-free ds_read_b128 (a stride-4 ds_read_b32 pattern is a 4-way bank conflict).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ inline void lds_read4(const float* arr, int lane, float (&o)[4]) {
+  constexpr int Q = OFF / 4, S = OFF % 4;
+  // the empty asm "uses" all four elements: it keeps the compiler from narrowing the loads to the
+  // elements actually consumed (ds_read_b32 / read2 at a 16-byte lane stride, which is exactly the
+  // conflicting pattern this helper avoids)
+  f32x4 A = *(const f32x4*)(arr + 4 * (lane + Q));
+  asm("" : "+v"(A));
+  const float a[4] = {A[0], A[1], A[2], A[3]};
+  if constexpr (S == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = a[i];
+  } else {
+    f32x4 B = *(const f32x4*)(arr + 4 * (lane + Q + 1));
+    asm("" : "+v"(B));
+    const float b[4] = {B[0], B[1], B[2], B[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (S + i < 4) ? a[(S + i) & 3] : b[(S + i) & 3];
+  }
+}
+
+// out[i] = prev_lane(sp[i]) + own + next_lane(pn[i]) for the lane's 4 columns: 8 v_add_f32_dpp.
+// One s_nop 1 covers the VALU-write -> DPP-read hazard of the operands (2 wait states).
+__device__ inline void window_combine4(const float (&sp)[4], float own, const float (&pn)[4], float (&o)[4]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %9, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %10, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %11, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %12, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(own), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]));
+}
+
+template <int BS, bool ACCUM, bool VEC4, int WAVE>
+__device__ __forceinline__ void wide_consume(const float* lds, float* __restrict__ out, int f, int dg, int lane,
+                                             int w_lo, int c_lo, int h_lo, int h_hi, int r_begin, int n_iters, int H,
+                                             int W, int D) {
+  constexpr int HALF = BS / 2;
+  constexpr int TAIL = BS - 1 - HALF;
+  constexpr int UNROLL = (BS == 9) ? 6 : (BS - 1);
+  constexpr int STEP = lcm_ce(UNROLL, kWRows);
+  const long HW = (long)H * W;
+  const int d_base = dg * kWDG + WAVE * kWND;
+  const int c0 = c_lo + kWCols * lane;         // unclamped first column of this lane
+  float* vol = out + (long)f * D * HW;
+  const bool lane_out = (lane >= 1) && (lane <= 62) && (c0 < W);
+  const float nf = (float)(BS * BS);
+
+  float P[kWND][kWCols][BS == 9 ? 2 : BS - 1];
+  float T[kWND][kWCols][BS == 9 ? 6 : 1];
+#pragma unroll
+  for (int j = 0; j < kWND; ++j)
+#pragma unroll
+    for (int i = 0; i < kWCols; ++i) {
+#pragma unroll
+      for (int k = 0; k < (BS == 9 ? 2 : BS - 1); ++k) P[j][i][k] = 0.f;
+#pragma unroll
+      for (int k = 0; k < (BS == 9 ? 6 : 1); ++k) T[j][i][k] = 0.f;
+    }
+
+  // All LDS operands of one product row (and of the output row it completes).
+  struct RowOps {
+    float a[4], ma[4], sa[4];
+    float b[kWND][4], mb[kWND][4], sb[kWND][4];
+  };
+  constexpr int kOff0 = (kWDG - 1) - WAVE * kWND;                  // span slot offset of disparity j = 0
+  auto load_row = [&](const float* pk) {
+    RowOps o;
+    lds_read4<0>(pk, lane, o.a);
+    lds_read4<0>(pk + kWTile, lane, o.ma);
+    lds_read4<0>(pk + 2 * kWTile, lane, o.sa);
+    lds_read4<kOff0>(pk + 3 * kWTile, lane, o.b[0]);
+    lds_read4<kOff0 - 1>(pk + 3 * kWTile, lane, o.b[1]);
+    lds_read4<kOff0>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[0]);
+    lds_read4<kOff0 - 1>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[1]);
+    lds_read4<kOff0>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[0]);
+    lds_read4<kOff0 - 1>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[1]);
+    return o;
+  };
+  static_assert(kWND == 2, "load_row spells out two disparities");
+
+  wg_barrier();                                                    // chunk 0 is in LDS
+  int chunk = 0;
+  for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < STEP; ++u) {
+      const int r = r_begin + it * STEP + u;
+      const bool last_of_chunk = (u % kWRows) == kWRows - 1;
+      // every LDS operand of the row is requested up front (15 ds_read_b128 in flight)
+      const RowOps cur = load_row(lds + ((chunk % kWBufs) * kWRows + (u % kWRows)) * kWPack);
+      float nma[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nma[i] = -nf * cur.ma[i];
+      const int h = r - TAIL;
+      const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
+#pragma unroll
+      for (int j = 0; j < kWND; ++j) {
+        float x[kWCols];
+#pragma unroll
+        for (int i = 0; i < kWCols; ++i) {
+          const float p = cur.a[i] * cur.b[j][i];
+          if constexpr (BS == 9) {
+            const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
+            P[j][i][u % 2] = p;
+            x[i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+            T[j][i][u % 6] = t3;
+          } else {
+            float v = p;
+#pragma unroll
+            for (int k = 0; k < BS - 1; ++k) v += P[j][i][k];
+            P[j][i][u % (BS - 1)] = p;
+            x[i] = v;
+          }
+        }
+        // horizontal window sums of the lane's 4 columns from prefix / suffix sums of the
+        // neighbouring lanes: out_i = suffix_prev(i - HALF + 4) + own(i-HALF .. i+TAIL) + prefix_next(i + TAIL - 4)
+        float pre[kWCols], suf[kWCols];                            // pre[k] = x0..xk, suf[k] = xk..x3
+        pre[0] = x[0];
+#pragma unroll
+        for (int k = 1; k < kWCols; ++k) pre[k] = pre[k - 1] + x[k];
+        suf[kWCols - 1] = x[kWCols - 1];
+#pragma unroll
+        for (int k = kWCols - 2; k >= 0; --k) suf[k] = suf[k + 1] + x[k];
+        float s[kWCols];
+        if constexpr (BS == 9) {
+          // window = previous lane's columns i..3, all four own columns, next lane's columns 0..i
+          window_combine4(suf, pre[kWCols - 1], pre, s);
+        } else {
+#pragma unroll
+          for (int i = 0; i < kWCols; ++i) {
+            const int lo = i - HALF, hi = i + TAIL;                // window in own-lane column units
+            const int o_lo = lo < 0 ? 0 : lo, o_hi = hi > kWCols - 1 ? kWCols - 1 : hi;
+            float own;
+            if (o_lo == 0) own = pre[o_hi];
+            else if (o_hi == kWCols - 1) own = suf[o_lo];
+            else { own = x[o_lo]; for (int k = o_lo + 1; k <= o_hi; ++k) own += x[k]; }
+            float acc = own;
+            if (lo < 0) acc = lane_prev1(suf[lo + kWCols]) + acc;  // previous lane's columns lo+4 .. 3
+            if (hi > kWCols - 1) acc = acc + lane_next1(pre[hi - kWCols]);   // next lane's columns 0 .. hi-4
+            s[i] = acc;
+          }
+        }
+        float val[kWCols];
+#pragma unroll
+        for (int i = 0; i < kWCols; ++i) {
+          const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
+          const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
+          val[i] = cov * __builtin_amdgcn_rcpf(den);
+        }
+        const int d = d_base + j;
+#if CTD_ABLATE == 1
+        if (row_out && lane_out && d < D && val[0] == 123456.789f) {
+#else
+        if (row_out && lane_out && d < D) {
+#endif
+#if CTD_ABLATE == 6
+          float* o = out + ((((long)d * HW + (long)h * W + c0) & 0x3FFFC) | ((long)(blockIdx.x + blockIdx.z) & 7) << 18);
+#else
+          float* o = vol + (long)d * HW + (long)h * W + c0;
+#endif
+          if constexpr (VEC4) {   // W % 4 == 0 and 16-byte aligned volume: c0 < W implies c0 + 3 < W
+            float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
+            if (ACCUM) {
+              const float4 old = *(const float4*)o;
+              v4.x += old.x; v4.y += old.y; v4.z += old.z; v4.w += old.w;
+            }
+            *(float4*)o = v4;
+          } else {
+#pragma unroll
+            for (int i = 0; i < kWCols; ++i)
+              if (c0 + i < W) o[i] = ACCUM ? o[i] + val[i] : val[i];
+          }
+        }
+      }
+      if (last_of_chunk) {
+        wait_lgkmcnt0();
+        wg_barrier();
+        ++chunk;
+      }
+    }
+  }
+}
+
+template <int BS, bool ACCUM, bool VEC4>
+__global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
+    const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
+    const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int W1, int xoff) {
+  constexpr int HALF = BS / 2;
+  constexpr int TAIL = BS - 1 - HALF;
+  static_assert(HALF <= kWCols && TAIL <= kWCols, "window must stay inside the neighbouring lanes");
+  constexpr int UNROLL = (BS == 9) ? 6 : (BS - 1);
+  constexpr int STEP = lcm_ce(UNROLL, kWRows);
+  extern __shared__ float lds[];               // [kWBufs][kWRows][kWPack]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
+  const int w_lo = blockIdx.x * kWOut;
+  const int h_lo = blockIdx.y * band_rows;
+  const int h_hi = min(h_lo + band_rows, H);
+  const long HW = (long)H * W;
+  const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
+  const int n_rows = r_end - r_begin + 1;
+  const int n_iters = (n_rows + STEP - 1) / STEP;
+  const int n_chunks = n_iters * (STEP / kWRows);
+
+  const float* a_img = ac + ((long)f * C + c) * HW;
+  const float* b_img = bc + (long)f * st1_frame_stride + (long)c * H * W1;
+  const float* m0i = m0 + ((long)f * C + c) * HW;
+  const float* v0i = v0 + ((long)f * C + c) * HW;
+  const float* m1i = m1 + (long)f * st1_frame_stride + (long)c * H * W1;
+  const float* v1i = v1 + (long)f * st1_frame_stride + (long)c * H * W1;
+  const int c_lo = w_lo - kWCols;                              // unclamped product column of slot 0
+  const int xb = c_lo - (dg * kWDG + kWDG - 1);                // unclamped pattern column of span slot 0
+
+  if (wave == kWWaves) {
+    // ------------------------------ loader wavefront ------------------------------
+    int acol[4], sc[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acol[k] = clampi(c_lo + 64 * k + lane, 0, W - 1);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sc[k] = clampi(xb + 64 * k + lane, -xoff, W - 1) + xoff;
+    const bool tail_lane = 4 * 64 + lane < kWSpan;
+    auto issue_chunk = [&](int chunk) {
+#if CTD_ABLATE == 5
+      return;
+#endif
+      float* buf = lds + (chunk % kWBufs) * (kWRows * kWPack);
+#pragma unroll
+      for (int s = 0; s < kWRows; ++s) {
+        const int r = r_begin + chunk * kWRows + s;
+        const int rc = clampi(r, 0, H - 1);
+        const int hs = clampi(r - TAIL, 0, H - 1);
+        float* pk = buf + s * kWPack;
+        const float* ar = a_img + (long)rc * W;
+        const float* br = b_img + (long)rc * W1;
+        const float* m0r = m0i + (long)hs * W;
+        const float* v0r = v0i + (long)hs * W;
+        const float* m1r = m1i + (long)hs * W1;
+        const float* v1r = v1i + (long)hs * W1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dma_dword(ar + acol[k], pk + 64 * k);
+          dma_dword(m0r + acol[k], pk + kWTile + 64 * k);
+          dma_dword(v0r + acol[k], pk + 2 * kWTile + 64 * k);
+          dma_dword(br + sc[k], pk + 3 * kWTile + 64 * k);
+          dma_dword(m1r + sc[k], pk + 3 * kWTile + kWSpanPad + 64 * k);
+          dma_dword(v1r + sc[k], pk + 3 * kWTile + 2 * kWSpanPad + 64 * k);
+        }
+        if (tail_lane) {
+          dma_dword(br + sc[4], pk + 3 * kWTile + 256);
+          dma_dword(m1r + sc[4], pk + 3 * kWTile + kWSpanPad + 256);
+          dma_dword(v1r + sc[4], pk + 3 * kWTile + 2 * kWSpanPad + 256);
+        }
+      }
+    };
+    constexpr int L = kWRows * kWDmaPerRow;                   // 54 DMA instructions per chunk
+    static_assert(L * (kWBufs - 2) < 64, "in-flight DMA count must fit vmcnt");
+#pragma unroll
+    for (int k = 0; k < kWBufs - 1; ++k)
+      if (k < n_chunks) issue_chunk(k);
+    if (n_chunks >= kWBufs - 1) wait_vmcnt<L*(kWBufs - 2)>(); else wait_vmcnt<0>();
+    wg_barrier();
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      const int nxt = ch + kWBufs - 1;
+      if (nxt < n_chunks) {
+        issue_chunk(nxt);
+        wait_vmcnt<L*(kWBufs - 2)>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      wg_barrier();
+    }
+    return;
+  }
+
+  // -------------------------------- consumer wavefronts --------------------------------
+  // the span offset of a wave's disparities is a compile-time constant of its wave index,
+  // which turns the unaligned 4-float pattern reads into aligned ds_read_b128 pairs
+  switch (wave) {
+    case 0: wide_consume<BS, ACCUM, VEC4, 0>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+    case 1: wide_consume<BS, ACCUM, VEC4, 1>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+    case 2: wide_consume<BS, ACCUM, VEC4, 2>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+    default: wide_consume<BS, ACCUM, VEC4, 3>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+  }
+}
+
 struct FastWorkspace {
-  float *m0, *v0, *m1, *v1;   // window mean / deviation planes of the frames and of the pattern
+  float *ac, *m0, *v0;        // centred frames, their window mean (centred) / deviation planes   [N*C][H][W]
+  float *bc, *m1, *v1;        // same for the pattern, per UNCLAMPED window-centre column          [..][H][W1]
   int W1, xoff;
   size_t bytes;
 };
@@ -344,11 +674,13 @@ static FastWorkspace fast_workspace(void* base, int frames, int C, int H, int W,
   size_t n0 = align_up((size_t)frames * C * H * W * sizeof(float), 256);
   size_t n1 = align_up((size_t)(per_frame_pattern ? frames : 1) * C * H * ws.W1 * sizeof(float), 256);
   char* p = (char*)base;
-  ws.m0 = (float*)p;
-  ws.v0 = (float*)(p + n0);
-  ws.m1 = (float*)(p + 2 * n0);
-  ws.v1 = (float*)(p + 2 * n0 + n1);
-  ws.bytes = 2 * n0 + 2 * n1;
+  ws.ac = (float*)p;
+  ws.m0 = (float*)(p + n0);
+  ws.v0 = (float*)(p + 2 * n0);
+  ws.bc = (float*)(p + 3 * n0);
+  ws.m1 = (float*)(p + 3 * n0 + n1);
+  ws.v1 = (float*)(p + 3 * n0 + 2 * n1);
+  ws.bytes = 3 * n0 + 3 * n1;
   return ws;
 }
 
@@ -357,40 +689,68 @@ size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, 
   return fast_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
 }
 
-static int launch_stats(const float* in, long frame_stride, int nimg, float* mean, float* dev, int H, int W, int x_start,
+static int launch_prepass(const float* in, long frame_stride, int nimg, float* cimg, float* mean, float* dev, int H,
+                          int W, int x_start,
                         int W_out, int bs, hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
-  if (lds > 64 * 1024) return CTD_ERR_UNSUPPORTED;
+  if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
   dim3 grid(ceil_div(W_out, kSTW), ceil_div(H, kSTH), nimg), block(kSTW, kSRows);
-  hipLaunchKernelGGL(ncc_window_stats_kernel, grid, block, lds, stream, in, frame_stride, mean, dev, H, W, x_start, W_out,
+  hipLaunchKernelGGL(ncc_prepass_kernel, grid, block, lds, stream, in, frame_stride, cimg, mean, dev, H, W, x_start, W_out,
                      bs);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
+}
+
+static int pick_bands(long wg_per_band, int H, int bs) {
+  // enough workgroups to fill 256 CUs a few times over, few enough that the (bs-1)-row
+  // warm-up of every band stays a small fraction of its rows
+  int bands = 1;
+  while (bands < 8 && wg_per_band * bands < 2048 && H / (bands * 2) >= 8 * (bs - 1)) bands *= 2;
+  return bands;
 }
 
 template <int BS>
 static int launch_fast(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
                        int W, int D, const FastWorkspace& ws, hipStream_t stream) {
   constexpr int WOUT = 64 - (BS - 1);
-  const int n_dgroups = ceil_div(D, kFDG);
-  // bands: enough workgroups to fill 256 CUs several times over, few enough that the
-  // (BS-1)-row warm-up of every band stays a small fraction of its rows
-  int bands = 1;
-  const long wg1 = (long)ceil_div(W, WOUT) * frames * n_dgroups;
-  while (bands < 8 && wg1 * bands < 2048 && H / (bands * 2) >= 8 * (BS - 1)) bands *= 2;
-  const int band_rows = ceil_div(H, bands);
-  dim3 grid(ceil_div(W, WOUT), ceil_div(H, band_rows), frames * n_dgroups), block(64 * (kFWaves + 1));
   const long st1_stride = in1_frame_stride ? (long)C * H * ws.W1 : 0;
-  const size_t lds = sizeof(float) * kFBufs * kFRows * kFPack;
+  // column split: full 248-column wide tiles (plus one more when the remainder is large),
+  // the rest in 64-(BS-1)-column narrow tiles
+  int n_wide = W / kWOut;
+  if (W - n_wide * kWOut > kWOut / 2) ++n_wide;
+  const int w_rem = n_wide * kWOut < W ? n_wide * kWOut : W;     // first column of the narrow part
   for (int c = 0; c < C; ++c) {
-    if (c == 0)
-      hipLaunchKernelGGL((ncc_fast_kernel<BS, false>), grid, block, lds, stream, in0, in1, in1_frame_stride, ws.m0,
-                         ws.v0, ws.m1, ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dgroups, ws.W1, ws.xoff);
-    else
-      hipLaunchKernelGGL((ncc_fast_kernel<BS, true>), grid, block, lds, stream, in0, in1, in1_frame_stride, ws.m0,
-                         ws.v0, ws.m1, ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dgroups, ws.W1, ws.xoff);
-    CTD_LAUNCH_CHECK();
+    if (n_wide > 0) {
+      const int n_dg = ceil_div(D, kWDG);
+      const int bands = pick_bands((long)n_wide * frames * n_dg, H, BS);
+      const int band_rows = ceil_div(H, bands);
+      dim3 grid(n_wide, ceil_div(H, band_rows), frames * n_dg), block(64 * (kWWaves + 1));
+      const size_t lds = sizeof(float) * kWBufs * kWRows * kWPack;
+      const bool vec4 = (W % 4 == 0) && (((uintptr_t)out) % 16 == 0);
+      auto kern = c == 0 ? (vec4 ? ncc_fast_wide_kernel<BS, false, true> : ncc_fast_wide_kernel<BS, false, false>)
+                         : (vec4 ? ncc_fast_wide_kernel<BS, true, true> : ncc_fast_wide_kernel<BS, true, false>);
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C,
+                         c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff);
+      CTD_LAUNCH_CHECK();
+    }
+    if (w_rem < W) {
+      const int n_dg = ceil_div(D, kFDG);
+      const int n_tiles = ceil_div(W - w_rem, WOUT);
+      const int bands = pick_bands((long)n_tiles * frames * n_dg, H, BS);
+      const int band_rows = ceil_div(H, bands);
+      dim3 grid(n_tiles, ceil_div(H, band_rows), frames * n_dg), block(64 * (kFWaves + 1));
+      const size_t lds = sizeof(float) * kFBufs * kFRows * kFPack;
+      if (c == 0)
+        hipLaunchKernelGGL((ncc_fast_kernel<BS, false>), grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1,
+                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff,
+                           w_rem);
+      else
+        hipLaunchKernelGGL((ncc_fast_kernel<BS, true>), grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1,
+                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff,
+                           w_rem);
+      CTD_LAUNCH_CHECK();
+    }
   }
   return CTD_OK;
 }
@@ -401,14 +761,14 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   const bool per_frame = in1_frame_stride != 0;
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
-  int st = launch_stats(in0, (long)H * W, frames * C, ws.m0, ws.v0, H, W, 0, W, bs, stream);
+  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, 0, W, bs, stream);
   if (st) return st;
   // pattern statistics per unclamped centre column x = w - d
   if (per_frame) {
     if (in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
-    st = launch_stats(in1, (long)H * W, frames * C, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
+    st = launch_prepass(in1, (long)H * W, frames * C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
   } else {
-    st = launch_stats(in1, (long)H * W, C, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
+    st = launch_prepass(in1, (long)H * W, C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
   }
   if (st) return st;
   switch (bs) {

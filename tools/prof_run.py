@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """Runs one hot-path kernel family a few times (profiling target for rocprofv3 --pmc passes)."""
 import sys, torch
 from connecting_the_dots_amd import torchext as te

@@ -1,3 +1,4 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time, torch, numpy as np
 from connecting_the_dots_amd import torchext as te
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
