@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the disparity hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--algo fast|exact] [--frames 16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = BASELINE config 2 on every rank: 16 synthetic 512x432 frames resident in HBM ->
+LCN (r=5, eps=0.05) -> zero-mean NCC block-matching volume against the LCN'd pattern over 128
+disparities (materialised, [16,128,432,512] f32) -> argmax over disparity with reference
+(bit-exact) indices.  Frames shard across ranks with no data-path collective (weak scaling);
+the only communication is the barrier / max-reduction of the timing itself.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, D, BS = 432, 512, 128, 9
+LCN_RADIUS, LCN_EPS = 5, 0.05
+BYTES_PER_PIXDISP = 4.0 + 8.0 / D          # 4*D*H*W volume write + both inputs read once
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+
+
+def make_inputs(frames, rank, device):
+    """Synthetic data of BASELINE.md section 3: RandomState(1234 + global frame index) uniform [0,1) frames,
+    the reference's seeded synthetic dot pattern (data/commons.py:8-11) as the pattern."""
+    from tests import workloads
+    a = np.stack([workloads.uniform_frame(1234 + rank * frames + i, H, W) for i in range(frames)])
+    pat = workloads.syn_dot_pattern(H, W, seed=42)[None, None]
+    return torch.from_numpy(a).to(device), torch.from_numpy(pat).to(device)
+
+
+def cpu_baseline(pattern_lcn_cpu, frame_lcn_cpu):
+    """The reference CPU path on a bounded sample: one frame of the same workload through the reference's own
+    xcorrvol_cpu (oracle/_ref, built from /root/reference by oracle/build_ref.py), else the C port."""
+    try:
+        from oracle import build_ref
+        ref = build_ref.load()
+    except Exception:
+        ref = None
+    a = frame_lcn_cpu.contiguous()
+    b = pattern_lcn_cpu.contiguous()
+    t0 = time.perf_counter()
+    if ref is not None:
+        torch.set_num_threads(1)
+        ref.xcorrvol_cpu(a, b, D, BS)
+        kind = "reference"
+    else:
+        from oracle import oracle
+        oracle.xcorrvol(a.numpy(), b.numpy(), D, BS, nthreads=1)
+        kind = "port"
+    dt = time.perf_counter() - t0
+    return {"value": H * W * D / dt / 1e6, "unit": "Mpix*disp/s", "cores": 1, "kind": kind,
+            "sample": "1 of the 16 frames of one step, full 512x432x128 NCC volume (xcorrvol_cpu, serial loop), "
+                      "%.1f s" % dt}
+
+
+def parity_probe(te, device):
+    """disparity MAE vs the reference on the committed full-size golden (seeds 1234 / 42)."""
+    try:
+        from tests import workloads
+        from tests.util import golden
+        g = golden("xcorrvol_cfg1")
+        a = torch.from_numpy(workloads.uniform_frame(1234, H, W)).to(device)
+        b = torch.from_numpy(workloads.uniform_frame(42, H, W)).to(device)
+        idx, _ = te.xcorrvol_argmax(a, b, D, BS)
+        return float(np.abs(idx.cpu().numpy().astype(np.int64) - g["uni_argmax"].astype(np.int64)).mean())
+    except Exception as e:           # golden fixtures not shipped
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step (BASELINE config 2: 16)")
+    ap.add_argument("--algo", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    os.environ["CTD_NCC_ALGO"] = args.algo
+    from connecting_the_dots_amd import _lib, torchext as te
+    L = _lib.lib()
+
+    frames, pattern = make_inputs(args.frames, rank, device)
+    pat_lcn, _ = te.lcn(pattern, LCN_RADIUS, LCN_EPS)        # once per run, as exp_synph.py:64-71 does
+    pat_lcn = pat_lcn[0].contiguous()
+
+    def step():
+        x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D, BS, return_volume=True)
+        return x, idx, vol
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.ctd_kernel_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x, idx, vol = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.ctd_kernel_timing_enable(0)
+    import ctypes
+    avg_ms, cols = ctypes.c_double(0), ctypes.c_int(0)
+    n_launch = L.ctd_kernel_timing_collect(ctypes.byref(avg_ms), ctypes.byref(cols))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        units_per_step = world * args.frames * H * W * D
+        value = units_per_step * args.steps / elapsed / 1e6
+        kernel_units = args.frames * H * cols.value * D
+        achieved = kernel_units * BYTES_PER_PIXDISP / (avg_ms.value * 1e-3) / 1e9 if n_launch else None
+        out = {
+            "metric": "Mpix*disparities/s on 512x432x128 cost volume; disparity MAE vs ref",
+            "value": value,
+            "unit": "Mpix*disp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: batch=16 512x432 frames per GPU, 128 disparities, block 9, "
+                                   "LCN(r=5,eps=0.05) + NCC cost volume (materialised) + argmax, algo=%s" % args.algo,
+                       "frames_per_gpu": args.frames, "H": H, "W": W, "D": D, "block_size": BS,
+                       "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+            "disparity_mae_vs_ref": parity_probe(te, device),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "ncc_fast_wide_kernel" if args.algo == "fast" else "ncc_exact_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "avg_launch_ms": avg_ms.value, "launches": n_launch,
+                "algorithmic_bytes_per_launch": kernel_units * BYTES_PER_PIXDISP,
+                "traffic": None,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[0].cpu())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,8 @@ _c_int, _c_long, _c_float, _c_size_t, _vp = (ctypes.c_int, ctypes.c_long, ctypes
 SIGNATURES = {
     "ctd_version": (_c_int, []),
     "ctd_status_string": (ctypes.c_char_p, [_c_int]),
+    "ctd_kernel_timing_enable": (None, [_c_int]),
+    "ctd_kernel_timing_collect": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
     "ctd_xcorrvol_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_xcorrvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 7 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_xcorrvol_f64": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),

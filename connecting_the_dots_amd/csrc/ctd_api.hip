@@ -2,11 +2,56 @@
 // Argument validation lives here; kernels assume validated shapes.
 #include "ctd_internal.h"
 
+#include <utility>
+#include <vector>
+
 using namespace ctd;
+
+namespace ctd {
+static bool g_timing = false;
+static int g_timing_columns = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
+static hipEvent_t g_pending = nullptr;
+bool timing_enabled() { return g_timing; }
+void timing_begin(hipStream_t stream) {
+  if (!g_timing) return;
+  if (hipEventCreate(&g_pending) != hipSuccess) { g_pending = nullptr; return; }
+  (void)hipEventRecord(g_pending, stream);
+}
+void timing_end(hipStream_t stream, int columns) {
+  if (!g_timing || !g_pending) return;
+  hipEvent_t stop;
+  if (hipEventCreate(&stop) != hipSuccess) return;
+  (void)hipEventRecord(stop, stream);
+  g_events.emplace_back(g_pending, stop);
+  g_pending = nullptr;
+  g_timing_columns = columns;
+}
+}  // namespace ctd
 
 extern "C" {
 
 int ctd_version(void) { return 1; }
+
+void ctd_kernel_timing_enable(int enable) { g_timing = enable != 0; }
+
+int ctd_kernel_timing_collect(double* avg_ms, int* columns) {
+  double total = 0;
+  int n = 0;
+  for (auto& ev : g_events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  g_events.clear();
+  if (avg_ms) *avg_ms = n ? total / n : 0.0;
+  if (columns) *columns = g_timing_columns;
+  return n;
+}
 
 const char* ctd_status_string(int status) {
   switch (status) {
@@ -79,7 +124,6 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
                             float* best, int frames, int C, int H, int W, int D, int block_size, int algo,
                             float rerank_eps, void* workspace, size_t workspace_bytes, int device, void* stream) {
-  (void)rerank_eps;
   if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
   if (C != 1) return CTD_ERR_UNSUPPORTED;
   if (frames == 0) return CTD_OK;
@@ -89,7 +133,15 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
   if (algo == CTD_NCC_EXACT)
     return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
                                 workspace_bytes, (hipStream_t)stream);
-  return CTD_ERR_UNSUPPORTED;
+  if (algo == CTD_NCC_FAST) {
+    if (!vol_out || !(rerank_eps >= 0.f)) return CTD_ERR_INVALID_ARG;   // the fast path ranks a materialised volume
+    int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
+                          workspace_bytes, (hipStream_t)stream);
+    if (st) return st;
+    return argmax_rerank_f32(vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
+                             (hipStream_t)stream);
+  }
+  return CTD_ERR_INVALID_ARG;
 }
 
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius, float eps, int device,

@@ -4,6 +4,11 @@
 
 namespace ctd {
 
+// kernel timing hooks (ctd_api.hip)
+bool timing_enabled();
+void timing_begin(hipStream_t stream);          // records the start event of the dominant kernel
+void timing_end(hipStream_t stream, int columns);
+
 // ncc_exact.hip
 size_t ncc_exact_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
 int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
@@ -19,6 +24,10 @@ int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int
 size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
+// argmax_rerank.hip
+int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
+                      float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream);
 
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);

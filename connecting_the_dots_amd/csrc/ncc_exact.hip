@@ -16,7 +16,7 @@
 //
 // This kernel is VALU-bound by construction (3 non-fusable f32 ops per tap per output,
 // >= 243 ops per output for bs = 9); the HBM-roofline kernel is ncc_fast.hip.
-#include "ctd_common.h"
+#include "ctd_internal.h"
 
 namespace ctd {
 
@@ -312,8 +312,10 @@ static int launch_exact_c(const float* in0, const float* in1, long in1_frame_str
   auto kern = ncc_exact_kernel<BS, WRITE_VOL, ARGMAX, MULTI_C>;
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  timing_begin(stream);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, in0, in1, in1_frame_stride, ws.stats0, ws.stats1, out, idx, best,
                      C, H, W, D);
+  timing_end(stream, W);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

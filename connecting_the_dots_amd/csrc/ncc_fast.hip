@@ -730,8 +730,10 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
       const bool vec4 = (W % 4 == 0) && (((uintptr_t)out) % 16 == 0);
       auto kern = c == 0 ? (vec4 ? ncc_fast_wide_kernel<BS, false, true> : ncc_fast_wide_kernel<BS, false, false>)
                          : (vec4 ? ncc_fast_wide_kernel<BS, true, true> : ncc_fast_wide_kernel<BS, true, false>);
+      timing_begin(stream);
       hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C,
                          c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff);
+      timing_end(stream, w_rem);
       CTD_LAUNCH_CHECK();
     }
     if (w_rem < W) {

@@ -40,6 +40,20 @@ enum ctd_status {
 int ctd_version(void);                       /* ABI version, currently 1 */
 const char* ctd_status_string(int status);
 
+/* --------------------------------------------------------------------------------------
+ * Per-kernel device timing for benchmarks (off by default, zero cost when off).
+ * When enabled, every launch of the dominant kernel of ctd_xcorrvol_f32 /
+ * ctd_xcorrvol_argmax_f32 (the NCC volume kernel proper, not its pre-pass) is bracketed by
+ * a pair of hipEvents recorded on the launch stream.  ctd_kernel_timing_collect()
+ * synchronises those events, returns the number of launches seen since the last collect
+ * and their average duration in milliseconds, and releases the events.
+ * `columns` receives the number of output columns per row that kernel covers (the
+ * remaining W - columns are produced by a secondary kernel), so that the caller can
+ * price the launch in algorithmic bytes.  Not thread-safe; meant for one bench process.
+ * -------------------------------------------------------------------------------------- */
+void ctd_kernel_timing_enable(int enable);
+int ctd_kernel_timing_collect(double* avg_ms, int* columns);
+
 /* photometric loss types -- torchext/ext/ext.h:196-199, torchext/functions.py:106-118 */
 #define CTD_PHOTOMETRIC_MSE 0
 #define CTD_PHOTOMETRIC_SAD 1
@@ -83,12 +97,14 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
                         int W, int device, void* stream);
 
 /* --------------------------------------------------------------------------------------
- * Fused NCC volume + argmax without materialising the volume (C == 1 only).
- *   vol_out may be NULL (no volume written) or [frames][D][H][W] (written as well).
- * With CTD_NCC_EXACT the indices equal torch.argmax(xcorrvol_cpu(...), 0) bit for bit.
- * With CTD_NCC_FAST the fast volume is ranked and every disparity whose fast score lies
- * within `rerank_eps` of the pixel's best is re-evaluated in reference order, so the
- * indices are those of the exact volume whenever |fast - exact| <= rerank_eps / 2.
+ * NCC volume + argmax over disparity (C == 1 only).
+ * CTD_NCC_EXACT: fused, vol_out may be NULL (no volume written) or [frames][D][H][W]
+ *   (written as well); indices equal torch.argmax(xcorrvol_cpu(...), 0) bit for bit and
+ *   best is the reference-order score.
+ * CTD_NCC_FAST: vol_out is required (the fast volume is materialised, then ranked in one
+ *   pass); every disparity whose fast score lies within `rerank_eps` of the pixel's best
+ *   is re-scored in reference order, so the indices are those of the reference-order
+ *   volume whenever |fast - exact| <= rerank_eps / 2 (D <= 512); best = vol_out[idx].
  * -------------------------------------------------------------------------------------- */
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,
                             float* vol_out, int64_t* idx, float* best, int frames, int C, int H,

@@ -82,3 +82,36 @@ def test_fast_multichannel_and_per_frame_pattern(te, oracle):
     vol = te.xcorrvol_batch(dev(a), dev(b), 20, 9, algo="fast").cpu().numpy()
     for f in range(2):
         assert_close(vol[f], oracle.xcorrvol(a[f], b[f], 20, 9, nthreads=4), rtol=1e-5, atol=3e-6, what="frame %d" % f)
+
+
+def test_fast_argmax_rerank_matches_reference_indices(te, oracle):
+    """algo='fast' + re-rank: indices bit-identical to torch.argmax of the reference-order volume."""
+    g = golden("xcorrvol_small")
+    n = 0
+    for k, (C, H, W, D, bs) in enumerate(g["cases"]):
+        if C != 1 or g["in0_%d" % k].dtype != np.float32 or bs % 2 == 0:
+            continue
+        n += 1
+        idx, best = te.xcorrvol_argmax(dev(g["in0_%d" % k]), dev(g["in1_%d" % k]), int(D), int(bs), algo="fast")
+        assert np.array_equal(idx.cpu().numpy(), g["argmax_%d" % k]), "case %d" % k
+        assert_close(best.cpu().numpy(), g["vol_%d" % k].max(0), what="best %d" % k)
+    assert n >= 3
+
+
+def test_fast_argmax_cfg1_full_size_bit_parity(te):
+    """BASELINE config 1/2 shape: disparity MAE vs reference == 0 on both golden workloads."""
+    g = golden("xcorrvol_cfg1")
+    a = workloads.uniform_frame(1234, 432, 512)
+    b = workloads.uniform_frame(42, 432, 512)
+    idx, best = te.xcorrvol_argmax(dev(a), dev(b), 128, 9, algo="fast")
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["uni_argmax"])
+
+
+def test_fast_argmax_kinect_bit_parity(te, oracle):
+    g = golden("xcorrvol_cfg1")
+    pat = g["kin_pattern_u8"].astype(np.float32) / 255
+    ir, _ = workloads.synth_ir(pat, np.random.RandomState(2024), 128)
+    ir_l, _ = oracle.lcn(ir[None, None], 5, 0.05)
+    pat_l, _ = oracle.lcn(pat[None, None], 5, 0.05)
+    idx, best = te.xcorrvol_argmax(dev(ir_l[0]), dev(pat_l[0]), 128, 9, algo="fast")
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["kin_argmax"])
