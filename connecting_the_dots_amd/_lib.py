@@ -24,6 +24,11 @@ SIGNATURES = {
     "ctd_argmax_disp_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_int, _vp]),
     "ctd_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 7 + [_c_float, _vp, _c_size_t,
                                                                                           _c_int, _vp]),
+    "ctd_photometric_fwd_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
+    "ctd_photometric_fwd_f64": (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
+    "ctd_photometric_bwd_f32": (_c_int, [_vp, _vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
+    "ctd_photometric_bwd_f64": (_c_int, [_vp, _vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
+    "ctd_costvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
     "ctd_lcn_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
 }
 

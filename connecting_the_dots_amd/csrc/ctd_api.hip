@@ -154,4 +154,45 @@ int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, i
   return lcn_f32(x, y, std_out, N, H, W, radius, eps, (hipStream_t)stream);
 }
 
+static bool photo_shape_ok(int B, int C, int H, int W, int bs, int type) {
+  return B >= 0 && C > 0 && H > 0 && W > 0 && bs > 0 && type >= 0 && type <= 3 &&
+         (double)B * C * H * W < 2147483648.0;                 // int indices in the reference (ext.h:220-235)
+}
+
+#define CTD_PHOTO_ENTRY(SFX, T)                                                                                   \
+  int ctd_photometric_fwd_##SFX(const T* es, const T* ta, T* out, int B, int C, int H, int W, int block_size,      \
+                                int type, float eps, int device, void* stream) {                                   \
+    if (!photo_shape_ok(B, C, H, W, block_size, type)) return CTD_ERR_INVALID_ARG;                                 \
+    if (B == 0) return CTD_OK;                                                                                     \
+    if (!es || !ta || !out) return CTD_ERR_INVALID_ARG;                                                            \
+    DeviceGuard g(device);                                                                                         \
+    if (g.status) return g.status;                                                                                 \
+    return photometric_fwd_##SFX(es, ta, out, B, C, H, W, block_size, type, eps, (hipStream_t)stream);             \
+  }                                                                                                                \
+  int ctd_photometric_bwd_##SFX(const T* es, const T* ta, const T* grad_out, T* grad_es, int B, int C, int H,      \
+                                int W, int block_size, int type, float eps, int device, void* stream) {            \
+    if (!photo_shape_ok(B, C, H, W, block_size, type)) return CTD_ERR_INVALID_ARG;                                 \
+    if (B == 0) return CTD_OK;                                                                                     \
+    if (!es || !ta || !grad_out || !grad_es) return CTD_ERR_INVALID_ARG;                                           \
+    DeviceGuard g(device);                                                                                         \
+    if (g.status) return g.status;                                                                                 \
+    return photometric_bwd_##SFX(es, ta, grad_out, grad_es, B, C, H, W, block_size, type, eps, (hipStream_t)stream); \
+  }
+CTD_PHOTO_ENTRY(f32, float)
+CTD_PHOTO_ENTRY(f64, double)
+#undef CTD_PHOTO_ENTRY
+
+int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,
+                    int W, int D, int block_size, int type, float eps, int device, void* stream) {
+  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0 ||
+      (long)frames * D > 65535)
+    return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!im || !pattern || !cost) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return costvol_f32(im, pattern, pattern_frame_stride, cost, frames, H, W, D, block_size, type, eps,
+                     (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -29,6 +29,18 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream);
 
+// photometric.hip
+int photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,
+                        float eps, hipStream_t s);
+int photometric_fwd_f64(const double* es, const double* ta, double* out, int B, int C, int H, int W, int bs, int type,
+                        float eps, hipStream_t s);
+int photometric_bwd_f32(const float* es, const float* ta, const float* go, float* gi, int B, int C, int H, int W,
+                        int bs, int type, float eps, hipStream_t s);
+int photometric_bwd_f64(const double* es, const double* ta, const double* go, double* gi, int B, int C, int H, int W,
+                        int bs, int type, float eps, hipStream_t s);
+int costvol_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W, int D,
+                int bs, int type, float eps, hipStream_t stream);
+
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 

@@ -182,3 +182,108 @@ def lcn(data, radius, epsilon):
                                 _stream(dev))
     _lib.check(st, "lcn")
     return y, std
+
+
+# --------------------------------------------------------------------------------------
+# Photometric block loss (reference: PhotometricLossFunction, functions.py:79-118)
+# --------------------------------------------------------------------------------------
+def _photo_args(es, ta):
+    _check(es, "es")
+    _check(ta, "ta")
+    if es.dim() != 4 or es.shape != ta.shape or es.dtype != ta.dtype:
+        raise RuntimeError("photometric_loss expects es and ta of the same [B,C,H,W] shape and dtype")
+    return _same_device(es, ta)
+
+
+class PhotometricLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, es, ta, block_size, type, eps):
+        dev = _photo_args(es, ta)
+        ctx.save_for_backward(es, ta)
+        ctx.block_size = block_size
+        ctx.type = type
+        ctx.eps = eps
+        B, C, H, W = es.shape
+        out = torch.empty((B, 1, H, W), dtype=es.dtype, device=dev)
+        L = _lib.lib()
+        fn = L.ctd_photometric_fwd_f32 if es.dtype == torch.float32 else L.ctd_photometric_fwd_f64
+        st = fn(_ptr(es), _ptr(ta), _ptr(out), B, C, H, W, int(block_size), int(type), float(eps), dev.index,
+                _stream(dev))
+        _lib.check(st, "photometric_loss_forward")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        es, ta = ctx.saved_tensors
+        grad_out = grad_out.contiguous()                      # functions.py:99
+        _check(grad_out, "grad_out")
+        dev = es.device
+        B, C, H, W = es.shape
+        # the gather backward writes every element: no zero-fill needed (the reference scatters into at::zeros)
+        grad_es = torch.empty_like(es)
+        L = _lib.lib()
+        fn = L.ctd_photometric_bwd_f32 if es.dtype == torch.float32 else L.ctd_photometric_bwd_f64
+        st = fn(_ptr(es), _ptr(ta), _ptr(grad_out), _ptr(grad_es), B, C, H, W, int(ctx.block_size), int(ctx.type),
+                float(ctx.eps), dev.index, _stream(dev))
+        _lib.check(st, "photometric_loss_backward")
+        return grad_es, None, None, None, None
+
+
+_PHOTO_TYPES = {"mse": 0, "sad": 1, "census_mse": 2, "census_sad": 3}
+
+
+def photometric_loss(es, ta, block_size, type='mse', eps=0.1):
+    """[B,C,H,W] x2 -> [B,1,H,W]: mean over a block_size^2 replicate-clamped block, summed over channels, of
+    (es-ta)^2 | |es-ta| | soft-census squared / absolute difference.  Gradient flows to `es` only."""
+    type = type.lower()
+    if type not in _PHOTO_TYPES:
+        raise Exception('invalid loss type')                  # functions.py:117
+    return PhotometricLossFunction.apply(es, ta, block_size, _PHOTO_TYPES[type], eps)
+
+
+def photometric_loss_pytorch(es, ta, block_size, type='mse', eps=0.1):
+    """Stock-PyTorch formulation of the same loss (replicate pad + unfold), kept as the independent
+    second opinion the reference ships next to its kernels (functions.py:120-147)."""
+    type = type.lower()
+    if type not in _PHOTO_TYPES:
+        raise Exception('invalid loss type')
+    p = block_size // 2
+    B, C, H, W = es.shape
+
+    def windows(x):
+        xp = torch.nn.functional.pad(x, (p, p, p, p), mode='replicate')
+        return torch.nn.functional.unfold(xp, kernel_size=block_size).view(B, C, -1, H, W)
+
+    ew, tw = windows(es), windows(ta)
+    if type in ('mse', 'sad'):
+        diff = ew - tw
+    else:
+        def soft(d):
+            return 0.5 * (1 + d / torch.sqrt(d * d + eps))
+        diff = soft(ew - es.unsqueeze(2)) - soft(tw - ta.unsqueeze(2))
+    term = diff * diff if type.endswith('mse') else diff.abs()
+    return term.reshape(B, -1, H, W).sum(dim=1, keepdim=True) / block_size ** 2
+
+
+def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1):
+    """Additive: SAD / MSE / soft-census block cost volume between frames and the pattern shifted by d
+    (SURVEY 8a/A6): cost[f,d] = photometric_loss(P_d, im[f]) with P_d[h,x] = P[h, clamp(x-d)].
+    im [N,H,W] | [H,W] f32, pattern [H,W] | [N,H,W] -> [N,D,H,W] | [D,H,W]; argmin over d is the best match."""
+    _check(im, "im", (torch.float32,))
+    _check(pattern, "pattern", (torch.float32,))
+    type = type.lower()
+    if type not in _PHOTO_TYPES:
+        raise Exception('invalid loss type')
+    squeeze = im.dim() == 2
+    a = im.unsqueeze(0) if squeeze else im
+    if a.dim() != 3 or pattern.dim() not in (2, 3) or tuple(pattern.shape[-2:]) != tuple(a.shape[-2:]):
+        raise RuntimeError("costvol expects im [N,H,W] or [H,W] and pattern [H,W] or [N,H,W]")
+    dev = _same_device(a, pattern)
+    N, H, W = a.shape
+    stride = 0 if pattern.dim() == 2 else H * W
+    D = int(n_disps)
+    out = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
+    st = _lib.lib().ctd_costvol_f32(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
+                                    _PHOTO_TYPES[type], float(eps), dev.index, _stream(dev))
+    _lib.check(st, "costvol")
+    return out[0] if squeeze else out

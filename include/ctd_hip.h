@@ -112,6 +112,35 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
                             void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* --------------------------------------------------------------------------------------
+ * Photometric block loss, forward and backward.
+ * Replaces photometric_loss_forward / photometric_loss_backward -- ext_cuda.cpp:92-123,
+ * kernels ext_kernel.cu:54-112, functors ext.h:201-344.
+ *   es, ta [B][C][H][W] -> out [B][1][H][W];  grad_out [B][1][H][W] -> grad_es [B][C][H][W]
+ * `eps` is a C float for both dtypes, as in the reference binding (ext_cuda.cpp:92).
+ * The backward is a deterministic gather (no atomics, no pre-zeroed buffer needed); the
+ * reference scatter-adds with atomicAdd into at::zeros (ext.h:315,338-339).
+ * -------------------------------------------------------------------------------------- */
+int ctd_photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H,
+                            int W, int block_size, int type, float eps, int device, void* stream);
+int ctd_photometric_bwd_f32(const float* es, const float* ta, const float* grad_out,
+                            float* grad_es, int B, int C, int H, int W, int block_size, int type,
+                            float eps, int device, void* stream);
+int ctd_photometric_fwd_f64(const double* es, const double* ta, double* out, int B, int C, int H,
+                            int W, int block_size, int type, float eps, int device, void* stream);
+int ctd_photometric_bwd_f64(const double* es, const double* ta, const double* grad_out,
+                            double* grad_es, int B, int C, int H, int W, int block_size, int type,
+                            float eps, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * SAD / soft-census cost volume, defined by composition of reference ops:
+ *   cost[d] = photometric_loss_forward(es = P_d, ta = I)[0,0],  P_d[h,x] = P[h, clamp(x-d)]
+ *   im [frames][H][W], pattern [H][W] (stride as above) -> cost [frames][D][H][W]
+ * -------------------------------------------------------------------------------------- */
+int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
+                    int frames, int H, int W, int D, int block_size, int type, float eps,
+                    int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
  * Local contrast normalisation, fused.  Replaces the op chain of LCN.tforward,
  * model/networks.py:507-533 (ReflectionPad2d + two all-ones Conv2d + 6 elementwise ops).
  *   x [N][1][H][W] -> y = (x-avg)/std, std  (both [N][1][H][W]);  radius < min(H, W)
