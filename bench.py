@@ -65,6 +65,20 @@ def cpu_baseline(pattern_lcn_cpu, frame_lcn_cpu):
                       "%.1f s" % dt}
 
 
+def measured_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc
+    passes of tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+    WRITE_SIZE as is, both in KiB).  None when no profile of this build has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    for name, c in json.load(open(files[-1])).items():
+        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def parity_probe(te, device):
     """disparity MAE vs the reference on the committed full-size golden (seeds 1234 / 42)."""
     try:
@@ -170,7 +184,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "avg_launch_ms": avg_ms.value, "launches": n_launch,
                 "algorithmic_bytes_per_launch": kernel_units * BYTES_PER_PIXDISP,
-                "traffic": None,
+                "traffic": measured_traffic("ncc_fast_wide_kernel" if args.algo == "fast" else "ncc_exact_kernel"),
             },
         }
         if not args.no_cpu_baseline:

@@ -1,0 +1,92 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/ctd_hip.h declares, the ctypes
+table matches the header, host-side argument validation works without a GPU, the Python surface mirrors the
+reference's torchext names."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ctd_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from connecting_the_dots_amd import _lib
+    from connecting_the_dots_amd import build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "libctd_hip.so does not export %s" % n
+
+
+def test_ctypes_table_matches_header():
+    from connecting_the_dots_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert _lib.lib().ctd_version() == 1
+    assert _lib.lib().ctd_status_string(1) == b"invalid argument"
+
+
+def test_workspace_query_and_validation_need_no_gpu():
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    assert L.ctd_xcorrvol_workspace_bytes(16, 1, 432, 512, 128, 9, 0) > 0
+    assert L.ctd_xcorrvol_workspace_bytes(16, 1, 432, 512, 128, 9, 1) >= L.ctd_xcorrvol_workspace_bytes(16, 1, 432, 512, 128, 9, 0)
+    assert L.ctd_xcorrvol_workspace_bytes(1, 1, 0, 512, 128, 9, 0) == 0
+    # invalid sizes are rejected before any HIP call
+    assert L.ctd_xcorrvol_f32(None, None, 0, None, 1, 1, -4, 8, 8, 9, 0, None, 0, -1, None) == 1
+    assert L.ctd_lcn_f32(None, None, None, 1, 8, 8, 8, 0.05, -1, None) == 1          # radius >= H
+    assert L.ctd_photometric_fwd_f32(None, None, None, 1, 1, 8, 8, 9, 7, 0.5, -1, None) == 1   # bad type
+    # 2^31 outputs exceed the reference's int indexing (common_cuda.h:65-66)
+    assert L.ctd_xcorrvol_f32(None, None, 0, None, 1, 1, 4096, 4096, 128, 9, 0, None, 0, -1, None) == 1
+
+
+def test_python_surface_mirrors_reference_names():
+    from connecting_the_dots_amd import torchext as te
+    for name in ("xcorrvol", "XCorrVolFunction", "photometric_loss", "PhotometricLossFunction",
+                 "photometric_loss_pytorch", "CoordConv2d"):
+        assert hasattr(te, name), name
+    for name in ("xcorrvol_batch", "xcorrvol_argmax", "argmax_disp", "lcn", "LCN", "costvol"):
+        assert hasattr(te, name), name
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from connecting_the_dots_amd import torchext as te
+    x = torch.rand(1, 8, 8)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        te.xcorrvol(x, x, 4, 9)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        te.photometric_loss(x[None], x[None], 9)
+    with pytest.raises(Exception, match="invalid loss type"):
+        te.photometric_loss(x[None], x[None], 9, "nope")
+
+
+def test_photometric_pytorch_formulation_matches_oracle(oracle):
+    """photometric_loss_pytorch runs on CPU tensors (stock ops) and agrees with the oracle."""
+    import numpy as np
+    from connecting_the_dots_amd import torchext as te
+    from tests.util import assert_close
+    rs = np.random.RandomState(3)
+    es, ta = rs.rand(1, 2, 12, 14), rs.rand(1, 2, 12, 14)
+    for ty, name in enumerate(("mse", "sad", "census_mse", "census_sad")):
+        got = te.photometric_loss_pytorch(torch.from_numpy(es), torch.from_numpy(ta), 9, name, 0.5).numpy()
+        assert_close(got, oracle.photometric_fwd(es, ta, 9, ty, 0.5), rtol=1e-10, atol=1e-12, what=name)
+
+
+def test_coordconv_grid():
+    from connecting_the_dots_amd import torchext as te
+    m = te.CoordConv2d(1, 2, 3, 1, 1)
+    y = m(torch.zeros(2, 1, 5, 7))
+    assert y.shape == (2, 2, 5, 7)
+    assert m.uv.shape == (1, 2, 5, 7)
+    assert float(m.uv[0, 0, 0, 0]) == -1 and float(m.uv[0, 0, 0, -1]) == 1       # u spans [-1, 1] (modules.py:19)
+    assert float(m.uv[0, 1, 0, 0]) == -1 and float(m.uv[0, 1, -1, 0]) == 1
