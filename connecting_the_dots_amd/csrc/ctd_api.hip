@@ -134,7 +134,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
                                 workspace_bytes, (hipStream_t)stream);
   if (algo == CTD_NCC_FAST) {
-    if (!vol_out || !(rerank_eps >= 0.f)) return CTD_ERR_INVALID_ARG;   // the fast path ranks a materialised volume
+    if (!vol_out || rerank_eps != rerank_eps) return CTD_ERR_INVALID_ARG;   // the fast path ranks a materialised volume; eps < 0 disables the re-rank
     int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
                           workspace_bytes, (hipStream_t)stream);
     if (st) return st;

@@ -104,7 +104,7 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
  * CTD_NCC_FAST: vol_out is required (the fast volume is materialised, then ranked in one
  *   pass); every disparity whose fast score lies within `rerank_eps` of the pixel's best
  *   is re-scored in reference order, so the indices are those of the reference-order
- *   volume whenever |fast - exact| <= rerank_eps / 2 (D <= 512); best = vol_out[idx].
+ *   volume whenever |fast - exact| <= rerank_eps / 2; best = vol_out[idx].
  * -------------------------------------------------------------------------------------- */
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,
                             float* vol_out, int64_t* idx, float* best, int frames, int C, int H,
