@@ -29,6 +29,9 @@
 // Window means / deviations (ma, sa, mb, sb) come from the same separable f64 pre-pass.
 #include "ctd_internal.h"
 
+#ifndef CTD_ABLATE2
+#define CTD_ABLATE2 0   // bit 0: no DPP combine, bit 1: no finalize, bit 2: no pattern-side LDS reads, bit 3: no vertical tree
+#endif
 #ifndef CTD_ABLATE
 #define CTD_ABLATE 0   // timing experiments only (tools); 0 in every shipped build
 #endif
@@ -161,6 +164,9 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 __device__ inline void dma_dword(const float* g, float* l) {   // LDS[l + 4*lane] <- *g (per-lane address)
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
 }
+__device__ inline void dma_quad(const float* g, float* l) {    // LDS[l + 16*lane .. +15] <- g[0..3] (16-byte aligned)
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
 
 constexpr int gcd_ce(int a, int b) { return b == 0 ? a : gcd_ce(b, a % b); }
 constexpr int lcm_ce(int a, int b) { return a / gcd_ce(a, b) * b; }
@@ -182,8 +188,8 @@ template <int BS, bool ACCUM>
 __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
-    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int W1, int xoff,
-    int w_start) {
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1,
+    int xoff, int w_start) {
   constexpr int HALF = BS / 2;
   constexpr int TAIL = BS - 1 - HALF;          // window rows/cols after the centre
   constexpr int WOUT = 64 - (BS - 1);          // output columns per wavefront
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
   const int n_iters = (n_rows + STEP - 1) / STEP;
   const int n_chunks = n_iters * (STEP / kFRows);
 
-  const float* a_img = ac + ((long)f * C + c) * HW;
+  const float* a_img = ac + ((long)f * C + c) * H * Wp + 4;      // +4: column c lives at c + 4
   const float* b_img = bc + (long)f * st1_frame_stride + (long)c * H * W1;
-  const float* m0i = m0 + ((long)f * C + c) * HW;
-  const float* v0i = v0 + ((long)f * C + c) * HW;
+  const float* m0i = m0 + ((long)f * C + c) * H * Wp + 4;
+  const float* v0i = v0 + ((long)f * C + c) * H * Wp + 4;
   const float* m1i = m1 + (long)f * st1_frame_stride + (long)c * H * W1;
   const float* v1i = v1 + (long)f * st1_frame_stride + (long)c * H * W1;
   const int xb = w_lo - HALF - (dg * kFDG + kFDG - 1);      // unclamped pattern column of span slot 0
@@ -224,9 +230,9 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
         const int rc = clampi(r, 0, H - 1);
         const int hs = clampi(r - TAIL, 0, H - 1);
         float* pk = buf + s * kFPack;
-        dma_dword(a_img + (long)rc * W + wa, pk);
-        dma_dword(m0i + (long)hs * W + wa, pk + 64);
-        dma_dword(v0i + (long)hs * W + wa, pk + 128);
+        dma_dword(a_img + (long)rc * Wp + wa, pk);
+        dma_dword(m0i + (long)hs * Wp + wa, pk + 64);
+        dma_dword(v0i + (long)hs * Wp + wa, pk + 128);
         dma_dword(b_img + (long)rc * W1 + sc0, pk + 192);
         dma_dword(m1i + (long)hs * W1 + sc0, pk + 192 + kFSpanPad);
         dma_dword(v1i + (long)hs * W1 + sc0, pk + 192 + 2 * kFSpanPad);
@@ -351,17 +357,29 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
 // which remains in use for the columns left over when W is not a multiple of 248.
 // ------------------------------------------------------------------------------------
 constexpr int kWCols = 4;                     // product columns per lane
-constexpr int kWND = 2;                       // disparities per lane
-constexpr int kWWaves = 4;                    // consumer wavefronts per workgroup
+#ifndef CTD_WND
+#define CTD_WND 2
+#endif
+constexpr int kWND = CTD_WND;                 // disparities per lane (1 or 2)
+#ifndef CTD_WWAVES
+#define CTD_WWAVES 4
+#endif
+#ifndef CTD_WROWS
+#define CTD_WROWS 2
+#endif
+#ifndef CTD_WBUFS
+#define CTD_WBUFS 3
+#endif
+constexpr int kWWaves = CTD_WWAVES;           // consumer wavefronts per workgroup (4 or 8)
 constexpr int kWDG = kWND * kWWaves;          // disparities per workgroup (8)
 constexpr int kWTile = 64 * kWCols;           // product columns per wavefront (256)
 constexpr int kWOut = 62 * kWCols;            // output columns per wavefront (248)
 constexpr int kWSpan = kWTile + kWDG - 1;     // 263 pattern columns per row
-constexpr int kWSpanPad = 264;
+constexpr int kWSpanPad = (kWSpan + 1 + 3) / 4 * 4;   // multiple of 4, > kWSpan
 constexpr int kWPack = 3 * kWTile + 3 * kWSpanPad;   // 1560 floats per staged row
-constexpr int kWRows = 2;                     // rows per LDS chunk
-constexpr int kWBufs = 3;                     // chunks in the ring
-constexpr int kWDmaPerRow = 3 * 4 + 3 * 5;    // 27 dword LDS-DMA instructions per row
+constexpr int kWRows = CTD_WROWS;             // rows per LDS chunk
+constexpr int kWBufs = CTD_WBUFS;             // chunks in the ring
+constexpr int kWDmaPerRow = 3 + 3 * 2;        // dwordx4 LDS-DMA instructions per row
 
 // Four floats starting OFF slots after the lane's own quad of a 16-byte aligned LDS array:
 // one or two conflict-free ds_read_b128 (a stride-4 ds_read_b32 pattern is a 4-way bank conflict).
@@ -443,15 +461,21 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
     lds_read4<0>(pk, lane, o.a);
     lds_read4<0>(pk + kWTile, lane, o.ma);
     lds_read4<0>(pk + 2 * kWTile, lane, o.sa);
+#if CTD_ABLATE2 & 4
+    for (int j = 0; j < kWND; ++j) for (int i = 0; i < 4; ++i) { o.b[j][i] = o.a[i] + j; o.mb[j][i] = o.ma[i]; o.sb[j][i] = o.sa[i]; }
+    return o;
+#endif
     lds_read4<kOff0>(pk + 3 * kWTile, lane, o.b[0]);
-    lds_read4<kOff0 - 1>(pk + 3 * kWTile, lane, o.b[1]);
     lds_read4<kOff0>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[0]);
-    lds_read4<kOff0 - 1>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[1]);
     lds_read4<kOff0>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[0]);
-    lds_read4<kOff0 - 1>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[1]);
+    if constexpr (kWND == 2) {
+      lds_read4<(kOff0 > 0 ? kOff0 - 1 : 0)>(pk + 3 * kWTile, lane, o.b[kWND - 1]);
+      lds_read4<(kOff0 > 0 ? kOff0 - 1 : 0)>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[kWND - 1]);
+      lds_read4<(kOff0 > 0 ? kOff0 - 1 : 0)>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[kWND - 1]);
+    }
     return o;
   };
-  static_assert(kWND == 2, "load_row spells out two disparities");
+  static_assert(kWND == 1 || kWND == 2, "load_row spells out one or two disparities");
 
   wg_barrier();                                                    // chunk 0 is in LDS
   int chunk = 0;
@@ -473,6 +497,9 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
 #pragma unroll
         for (int i = 0; i < kWCols; ++i) {
           const float p = cur.a[i] * cur.b[j][i];
+#if CTD_ABLATE2 & 8
+          x[i] = p + P[j][i][0]; P[j][i][0] = p;
+#else
           if constexpr (BS == 9) {
             const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
             P[j][i][u % 2] = p;
@@ -485,6 +512,7 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
             P[j][i][u % (BS - 1)] = p;
             x[i] = v;
           }
+#endif
         }
         // horizontal window sums of the lane's 4 columns from prefix / suffix sums of the
         // neighbouring lanes: out_i = suffix_prev(i - HALF + 4) + own(i-HALF .. i+TAIL) + prefix_next(i + TAIL - 4)
@@ -498,7 +526,11 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
         float s[kWCols];
         if constexpr (BS == 9) {
           // window = previous lane's columns i..3, all four own columns, next lane's columns 0..i
+#if CTD_ABLATE2 & 1
+          for (int i = 0; i < 4; ++i) s[i] = suf[i] + pre[i];
+#else
           window_combine4(suf, pre[kWCols - 1], pre, s);
+#endif
         } else {
 #pragma unroll
           for (int i = 0; i < kWCols; ++i) {
@@ -517,9 +549,13 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
         float val[kWCols];
 #pragma unroll
         for (int i = 0; i < kWCols; ++i) {
+#if CTD_ABLATE2 & 2
+          val[i] = s[i] + nma[i];
+#else
           const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
           const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
           val[i] = cov * __builtin_amdgcn_rcpf(den);
+#endif
         }
         const int d = d_base + j;
 #if CTD_ABLATE == 1
@@ -559,7 +595,8 @@ template <int BS, bool ACCUM, bool VEC4>
 __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
-    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int W1, int xoff) {
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1,
+    int xoff) {
   constexpr int HALF = BS / 2;
   constexpr int TAIL = BS - 1 - HALF;
   static_assert(HALF <= kWCols && TAIL <= kWCols, "window must stay inside the neighbouring lanes");
@@ -572,16 +609,15 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
   const int w_lo = blockIdx.x * kWOut;
   const int h_lo = blockIdx.y * band_rows;
   const int h_hi = min(h_lo + band_rows, H);
-  const long HW = (long)H * W;
   const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
   const int n_rows = r_end - r_begin + 1;
   const int n_iters = (n_rows + STEP - 1) / STEP;
   const int n_chunks = n_iters * (STEP / kWRows);
 
-  const float* a_img = ac + ((long)f * C + c) * HW;
+  const float* a_img = ac + ((long)f * C + c) * H * Wp + 4;      // +4: column c lives at c + 4
   const float* b_img = bc + (long)f * st1_frame_stride + (long)c * H * W1;
-  const float* m0i = m0 + ((long)f * C + c) * HW;
-  const float* v0i = v0 + ((long)f * C + c) * HW;
+  const float* m0i = m0 + ((long)f * C + c) * H * Wp + 4;
+  const float* v0i = v0 + ((long)f * C + c) * H * Wp + 4;
   const float* m1i = m1 + (long)f * st1_frame_stride + (long)c * H * W1;
   const float* v1i = v1 + (long)f * st1_frame_stride + (long)c * H * W1;
   const int c_lo = w_lo - kWCols;                              // unclamped product column of slot 0
@@ -589,12 +625,13 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 
   if (wave == kWWaves) {
     // ------------------------------ loader wavefront ------------------------------
-    int acol[4], sc[5];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acol[k] = clampi(c_lo + 64 * k + lane, 0, W - 1);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) sc[k] = clampi(xb + 64 * k + lane, -xoff, W - 1) + xoff;
-    const bool tail_lane = 4 * 64 + lane < kWSpan;
+    // 16 bytes per lane and DMA: one instruction moves a whole 256-column array row.  All sources are
+    // 16-byte aligned by construction (padded planes, see fast_workspace); lanes past the image are
+    // clamped to the last quad, which only ever feeds columns that produce no output.
+    const int aq = min(c_lo + kWCols * lane, Wp - 8);                         // frame quad of this lane (>= -4)
+    const int sq0 = min(xb + xoff + kWCols * lane, W1 - kWCols);              // pattern quad, slots 0..255
+    const int sq1 = min(xb + xoff + kWTile + kWCols * lane, W1 - kWCols);     // slots 256.. (first 2 lanes)
+    const bool tail_lane = kWTile + kWCols * lane < kWSpan;
     auto issue_chunk = [&](int chunk) {
 #if CTD_ABLATE == 5
       return;
@@ -606,29 +643,20 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
         const int rc = clampi(r, 0, H - 1);
         const int hs = clampi(r - TAIL, 0, H - 1);
         float* pk = buf + s * kWPack;
-        const float* ar = a_img + (long)rc * W;
-        const float* br = b_img + (long)rc * W1;
-        const float* m0r = m0i + (long)hs * W;
-        const float* v0r = v0i + (long)hs * W;
-        const float* m1r = m1i + (long)hs * W1;
-        const float* v1r = v1i + (long)hs * W1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          dma_dword(ar + acol[k], pk + 64 * k);
-          dma_dword(m0r + acol[k], pk + kWTile + 64 * k);
-          dma_dword(v0r + acol[k], pk + 2 * kWTile + 64 * k);
-          dma_dword(br + sc[k], pk + 3 * kWTile + 64 * k);
-          dma_dword(m1r + sc[k], pk + 3 * kWTile + kWSpanPad + 64 * k);
-          dma_dword(v1r + sc[k], pk + 3 * kWTile + 2 * kWSpanPad + 64 * k);
-        }
+        dma_quad(a_img + (long)rc * Wp + aq, pk);
+        dma_quad(m0i + (long)hs * Wp + aq, pk + kWTile);
+        dma_quad(v0i + (long)hs * Wp + aq, pk + 2 * kWTile);
+        dma_quad(b_img + (long)rc * W1 + sq0, pk + 3 * kWTile);
+        dma_quad(m1i + (long)hs * W1 + sq0, pk + 3 * kWTile + kWSpanPad);
+        dma_quad(v1i + (long)hs * W1 + sq0, pk + 3 * kWTile + 2 * kWSpanPad);
         if (tail_lane) {
-          dma_dword(br + sc[4], pk + 3 * kWTile + 256);
-          dma_dword(m1r + sc[4], pk + 3 * kWTile + kWSpanPad + 256);
-          dma_dword(v1r + sc[4], pk + 3 * kWTile + 2 * kWSpanPad + 256);
+          dma_quad(b_img + (long)rc * W1 + sq1, pk + 3 * kWTile + kWTile);
+          dma_quad(m1i + (long)hs * W1 + sq1, pk + 3 * kWTile + kWSpanPad + kWTile);
+          dma_quad(v1i + (long)hs * W1 + sq1, pk + 3 * kWTile + 2 * kWSpanPad + kWTile);
         }
       }
     };
-    constexpr int L = kWRows * kWDmaPerRow;                   // 54 DMA instructions per chunk
+    constexpr int L = kWRows * kWDmaPerRow;                   // DMA instructions per chunk
     static_assert(L * (kWBufs - 2) < 64, "in-flight DMA count must fit vmcnt");
 #pragma unroll
     for (int k = 0; k < kWBufs - 1; ++k)
@@ -651,27 +679,36 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
   // -------------------------------- consumer wavefronts --------------------------------
   // the span offset of a wave's disparities is a compile-time constant of its wave index,
   // which turns the unaligned 4-float pattern reads into aligned ds_read_b128 pairs
+#define CTD_WCASE(WV) \
+  case WV: wide_consume<BS, ACCUM, VEC4, (WV < kWWaves ? WV : 0)>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
   switch (wave) {
-    case 0: wide_consume<BS, ACCUM, VEC4, 0>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
-    case 1: wide_consume<BS, ACCUM, VEC4, 1>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
-    case 2: wide_consume<BS, ACCUM, VEC4, 2>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
-    default: wide_consume<BS, ACCUM, VEC4, 3>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+    CTD_WCASE(0) CTD_WCASE(1) CTD_WCASE(2) CTD_WCASE(3)
+#if CTD_WWAVES > 4
+    CTD_WCASE(4) CTD_WCASE(5) CTD_WCASE(6) CTD_WCASE(7)
+#endif
+    default: break;
   }
+#undef CTD_WCASE
 }
 
 struct FastWorkspace {
   float *ac, *m0, *v0;        // centred frames, their window mean (centred) / deviation planes   [N*C][H][W]
   float *bc, *m1, *v1;        // same for the pattern, per UNCLAMPED window-centre column          [..][H][W1]
-  int W1, xoff;
+  int Wp;                     // frame plane row pitch: W + 8, column c lives at c + 4 (replicate border baked in)
+  int W1, xoff;               // pattern plane row pitch and origin: column x lives at x + xoff
   size_t bytes;
 };
 
 static FastWorkspace fast_workspace(void* base, int frames, int C, int H, int W, int D, bool per_frame_pattern) {
   FastWorkspace ws;
   const int Dpad = (D + kFDG - 1) / kFDG * kFDG;
-  ws.xoff = Dpad - 1;                     // x = w - d ranges over [-(Dpad-1), W-1]
-  ws.W1 = W + ws.xoff;
-  size_t n0 = align_up((size_t)frames * C * H * W * sizeof(float), 256);
+  // x = w - d ranges over [-(Dpad-1) - 4, W + 3] (4 halo columns either side).  xoff = 3 (mod 4) makes
+  // the first span slot of every workgroup 16-byte aligned (w_lo and the disparity-group base are
+  // multiples of 4), which the dwordx4 LDS-DMA of the wide kernel relies on.
+  ws.xoff = Dpad + 3;
+  ws.W1 = (int)align_up((size_t)(W + 4 + ws.xoff), 4);
+  ws.Wp = (int)align_up((size_t)(W + 8), 4);
+  size_t n0 = align_up((size_t)frames * C * H * ws.Wp * sizeof(float), 256);
   size_t n1 = align_up((size_t)(per_frame_pattern ? frames : 1) * C * H * ws.W1 * sizeof(float), 256);
   char* p = (char*)base;
   ws.ac = (float*)p;
@@ -732,7 +769,7 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
                          : (vec4 ? ncc_fast_wide_kernel<BS, true, true> : ncc_fast_wide_kernel<BS, true, false>);
       timing_begin(stream);
       hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C,
-                         c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff);
+                         c, H, W, D, band_rows, n_dg, ws.Wp, ws.W1, ws.xoff);
       timing_end(stream, w_rem);
       CTD_LAUNCH_CHECK();
     }
@@ -745,12 +782,12 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
       const size_t lds = sizeof(float) * kFBufs * kFRows * kFPack;
       if (c == 0)
         hipLaunchKernelGGL((ncc_fast_kernel<BS, false>), grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1,
-                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff,
-                           w_rem);
+                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.Wp, ws.W1,
+                           ws.xoff, w_rem);
       else
         hipLaunchKernelGGL((ncc_fast_kernel<BS, true>), grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1,
-                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.W1, ws.xoff,
-                           w_rem);
+                           ws.v1, st1_stride, out, C, c, H, W, D, band_rows, n_dg, ws.Wp, ws.W1,
+                           ws.xoff, w_rem);
       CTD_LAUNCH_CHECK();
     }
   }
@@ -763,7 +800,7 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   const bool per_frame = in1_frame_stride != 0;
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
-  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, 0, W, bs, stream);
+  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, -4, ws.Wp, bs, stream);
   if (st) return st;
   // pattern statistics per unclamped centre column x = w - d
   if (per_frame) {

@@ -5,7 +5,12 @@
 // MODE 0: wide-kernel pattern: block = 4 waves x 2 disparities, wave writes 992 B per (d, h) row, tiles of 248 columns
 // MODE 1: same but a block covers both column tiles (8 waves: 2 tiles x 4 d-pairs) -> 2 KB contiguous per (d,h)
 // MODE 2: fully sequential: every wave streams a contiguous slab (1 KB per instruction)
-template <int MODE>
+__device__ inline float spin4(float x, int spin) {
+  float a = x, b = x + 1, c = x + 2, d = x + 3;
+  for (int s = 0; s < spin; ++s) { a = a * 1.0001f + 0.5f; b = b * 1.0001f + 0.5f; c = c * 1.0001f + 0.5f; d = d * 1.0001f + 0.5f; }
+  return a + b + c + d;
+}
+template <int MODE, bool NT = false>
 __global__ void k(float* out, int H, int W, int D, int band_rows, int n_dg, int spin) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long HW = (long)H * W;
@@ -30,19 +35,24 @@ __global__ void k(float* out, int H, int W, int D, int band_rows, int n_dg, int 
   const bool lane_out = (MODE == 3 || MODE == 4) ? true : (lane >= 1 && lane <= 62 && c0 < W);
   float* vol = out + (long)f * D * HW;
   for (int h = h_lo; h < h_hi; ++h) {
-    float x = (float)h; for (int s = 0; s < spin; ++s) x = x * 1.0001f + 0.5f;
+    float x = spin4((float)h, spin);
     for (int j = 0; j < 2; ++j) {
       int d = MODE == 4 ? (dg * 8 + w4 + 4 * j) : (dg * 8 + w4 * 2 + j);
-      if (lane_out) *(float4*)(vol + (long)d * HW + (long)h * W + c0) = make_float4(x, 1.f, 2.f, 3.f);
+      if (lane_out) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v = {x, 1.f, 2.f, 3.f};
+        f4* o = (f4*)(vol + (long)d * HW + (long)h * W + c0);
+        if (NT) __builtin_nontemporal_store(v, o); else *o = v;
+      }
     }
   }
 }
-template <int MODE> void run(const char* name, float* d, int N, int H, int W, int D, int spin) {
+template <int MODE, bool NT = false> void run(const char* name, float* d, int N, int H, int W, int D, int spin) {
   int n_dg = D / 8, bands = 4, band_rows = (H + bands - 1) / bands;
   dim3 grid(MODE == 1 ? 1 : 2, bands, N * n_dg), block(MODE == 1 ? 512 : 256);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE><<<grid, block>>>(d, H, W, D, band_rows, n_dg, spin); hipDeviceSynchronize();
-  hipEventRecord(e0); for (int i = 0; i < 5; ++i) k<MODE><<<grid, block>>>(d, H, W, D, band_rows, n_dg, spin); hipEventRecord(e1); hipEventSynchronize(e1);
+  k<MODE, NT><<<grid, block>>>(d, H, W, D, band_rows, n_dg, spin); hipDeviceSynchronize();
+  hipEventRecord(e0); for (int i = 0; i < 5; ++i) k<MODE, NT><<<grid, block>>>(d, H, W, D, band_rows, n_dg, spin); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
   double bytes = (double)N * D * H * ((MODE == 2 || MODE == 3 || MODE == 4) ? W : 496) * 4;
   printf("%-28s spin=%3d %8.3f ms  %.2f TB/s  (%.1f us/frame)\n", name, spin, ms, bytes / ms / 1e9, ms * 1e3 / N);
@@ -50,12 +60,11 @@ template <int MODE> void run(const char* name, float* d, int N, int H, int W, in
 int main() {
   int N = 16, H = 432, W = 512, D = 128;
   float* d; hipMalloc(&d, (size_t)N * D * H * W * 4);
-  for (int spin : {0, 64}) {
+  for (int spin : {0, 50, 100, 200}) {
     run<0>("wide pattern (992 B pieces)", d, N, H, W, D, spin);
-    run<1>("full-row blocks (2 KB)", d, N, H, W, D, spin);
-    run<2>("sequential slabs", d, N, H, W, D, spin);
+    run<0, true>("wide pattern, nontemporal", d, N, H, W, D, spin);
     run<3>("aligned 1 KB pieces", d, N, H, W, D, spin);
-    run<4>("aligned 1 KB, d strided by 4", d, N, H, W, D, spin);
+    run<3, true>("aligned 1 KB, nontemporal", d, N, H, W, D, spin);
   }
   return 0;
 }
