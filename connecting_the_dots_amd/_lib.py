@@ -30,6 +30,14 @@ SIGNATURES = {
     "ctd_photometric_bwd_f64": (_c_int, [_vp, _vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
     "ctd_costvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
     "ctd_lcn_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
+    "ctd_disp_to_depth_fwd_f32": (_c_int, [_vp, _vp, _c_long, _c_float, _c_int, _vp]),
+    "ctd_disp_to_depth_bwd_f32": (_c_int, [_vp, _vp, _vp, _c_long, _c_float, _c_int, _vp]),
+    "ctd_disparity_loss_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "ctd_disparity_loss_fwd_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 3 + [_vp, _c_size_t, _c_int, _vp]),
+    "ctd_disparity_loss_bwd_f32": (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp, _c_size_t, _c_int, _vp]),
+    "ctd_geometric_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "ctd_geometric_fwd_f32": (_c_int, [_vp] * 9 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
+    "ctd_geometric_bwd_f32": (_c_int, [_vp] * 10 + [_c_int, _vp] + [_c_int] * 3 + [_c_float, _c_int, _vp]),
 }
 
 _lib = None

@@ -195,4 +195,77 @@ int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_st
                      (hipStream_t)stream);
 }
 
+int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float baseline_focal, int device, void* stream) {
+  if (n < 0) return CTD_ERR_INVALID_ARG;
+  if (n == 0) return CTD_OK;
+  if (!disp || !depth) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return disp_to_depth_fwd_f32(disp, depth, n, baseline_focal, (hipStream_t)stream);
+}
+
+int ctd_disp_to_depth_bwd_f32(const float* disp, const float* grad_depth, float* grad_disp, long n,
+                              float baseline_focal, int device, void* stream) {
+  if (n < 0) return CTD_ERR_INVALID_ARG;
+  if (n == 0) return CTD_OK;
+  if (!disp || !grad_depth || !grad_disp) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return disp_to_depth_bwd_f32(disp, grad_depth, grad_disp, n, baseline_focal, (hipStream_t)stream);
+}
+
+static bool img_shape_ok(int B, int H, int W) {
+  return B > 0 && H > 0 && W > 0 && B <= 65535 && (double)B * H * W < 2147483648.0;
+}
+
+size_t ctd_disparity_loss_workspace_bytes(int B, int H, int W) {
+  return img_shape_ok(B, H, W) ? disparity_loss_workspace_bytes(B, H, W) : 0;
+}
+
+int ctd_disparity_loss_fwd_f32(const float* disp, const float* edge, float* loss, int B, int H, int W, void* workspace,
+                               size_t workspace_bytes, int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || !disp || !loss) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return disparity_loss_fwd_f32(disp, edge, loss, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ctd_disparity_loss_bwd_f32(const float* disp, const float* edge, const float* grad_loss, float* grad_disp,
+                               float* grad_edge, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                               int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || !disp || !grad_loss || !grad_disp) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return disparity_loss_bwd_f32(disp, edge, grad_loss, grad_disp, grad_edge, B, H, W, workspace, workspace_bytes,
+                                (hipStream_t)stream);
+}
+
+size_t ctd_geometric_workspace_bytes(int B, int H, int W) {
+  return img_shape_ok(B, H, W) ? geometric_workspace_bytes(B, H, W) : 0;
+}
+
+int ctd_geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                          const float* t0, const float* R1, const float* t1, float* loss, int accumulate, int B, int H,
+                          int W, float clamp, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || H < 2 || W < 2 || !depth0 || !depth1 || !ray || !K || !R0 || !t0 || !R1 || !t1 || !loss)
+    return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return geometric_fwd_f32(depth0, depth1, ray, K, R0, t0, R1, t1, loss, accumulate, B, H, W, clamp, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
+int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                          const float* t0, const float* R1, const float* t1, const float* grad_loss,
+                          float* grad_depth0, int accumulate0, float* grad_depth1, int B, int H, int W, float clamp,
+                          int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || H < 2 || W < 2 || !depth0 || !depth1 || !ray || !K || !R0 || !t0 || !R1 || !t1 ||
+      !grad_loss || !grad_depth0 || !grad_depth1)
+    return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return geometric_bwd_f32(depth0, depth1, ray, K, R0, t0, R1, t1, grad_loss, grad_depth0, accumulate0, grad_depth1, B,
+                           H, W, clamp, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -44,4 +44,20 @@ int costvol_f32(const float* im, const float* pat, long pat_frame_stride, float*
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 
+// losses.hip
+int disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bf, hipStream_t s);
+int disp_to_depth_bwd_f32(const float* disp, const float* go, float* gi, long n, float bf, hipStream_t s);
+size_t disparity_loss_workspace_bytes(int B, int H, int W);
+int disparity_loss_fwd_f32(const float* disp, const float* edge, float* loss, int B, int H, int W, void* ws,
+                           size_t ws_bytes, hipStream_t s);
+int disparity_loss_bwd_f32(const float* disp, const float* edge, const float* grad_loss, float* grad_disp,
+                           float* grad_edge, int B, int H, int W, void* ws, size_t ws_bytes, hipStream_t s);
+size_t geometric_workspace_bytes(int B, int H, int W);
+int geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                      const float* t0, const float* R1, const float* t1, float* loss, int accumulate, int B, int H,
+                      int W, float clamp, void* ws, size_t ws_bytes, hipStream_t s);
+int geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                      const float* t0, const float* R1, const float* t1, const float* grad_loss, float* grad_depth0,
+                      int accumulate0, float* grad_depth1, int B, int H, int W, float clamp, hipStream_t s);
+
 }  // namespace ctd

@@ -287,3 +287,138 @@ def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1):
                                     _PHOTO_TYPES[type], float(eps), dev.index, _stream(dev))
     _lib.check(st, "costvol")
     return out[0] if squeeze else out
+
+
+# --------------------------------------------------------------------------------------
+# Fused loss kernels (reference: stock-PyTorch modules of model/networks.py; additive API)
+# --------------------------------------------------------------------------------------
+def _f32(t, name):
+    _check(t, name, (torch.float32,))
+    return t
+
+
+class DispToDepthFunction(torch.autograd.Function):
+    """depth = baseline_focal / (relu(disp) + 1e-12)   (networks.DispToDepth.tforward, networks.py:318-321)"""
+
+    @staticmethod
+    def forward(ctx, disp, baseline_focal):
+        disp = _f32(disp.contiguous(), "disp")
+        ctx.save_for_backward(disp)
+        ctx.bf = float(baseline_focal)
+        depth = torch.empty_like(disp)
+        dev = disp.device
+        st = _lib.lib().ctd_disp_to_depth_fwd_f32(_ptr(disp), _ptr(depth), disp.numel(), ctx.bf, dev.index, _stream(dev))
+        _lib.check(st, "disp_to_depth")
+        return depth
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        (disp,) = ctx.saved_tensors
+        grad_depth = _f32(grad_depth.contiguous(), "grad_depth")
+        grad = torch.empty_like(disp)
+        dev = disp.device
+        st = _lib.lib().ctd_disp_to_depth_bwd_f32(_ptr(disp), _ptr(grad_depth), _ptr(grad), disp.numel(), ctx.bf,
+                                                  dev.index, _stream(dev))
+        _lib.check(st, "disp_to_depth backward")
+        return grad, None
+
+
+def disp_to_depth(disp, baseline_focal):
+    return DispToDepthFunction.apply(disp, baseline_focal)
+
+
+class DisparityLossFunction(torch.autograd.Function):
+    """Sobel 5x5 + edge-aware disparity loss (networks.DisparityLoss.tforward, networks.py:395-412) -> scalar."""
+
+    @staticmethod
+    def forward(ctx, disp, edge):
+        disp = _f32(disp.contiguous(), "disp")
+        if disp.dim() != 4 or disp.shape[1] != 1:
+            raise RuntimeError("disparity_loss expects disp [B,1,H,W]")
+        if edge is not None:
+            edge = _f32(edge.contiguous(), "edge")
+            if edge.shape != disp.shape:
+                raise RuntimeError("edge must have the shape of disp")
+            _same_device(disp, edge)
+        B, _, H, W = disp.shape
+        dev = disp.device
+        L = _lib.lib()
+        ws = _workspace(L.ctd_disparity_loss_workspace_bytes(B, H, W), dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        st = L.ctd_disparity_loss_fwd_f32(_ptr(disp), _ptr(edge), _ptr(loss), B, H, W, _ptr(ws), ws.numel(), dev.index,
+                                          _stream(dev))
+        _lib.check(st, "disparity_loss")
+        ctx.save_for_backward(disp, edge)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        disp, edge = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        dev = disp.device
+        L = _lib.lib()
+        ws = _workspace(L.ctd_disparity_loss_workspace_bytes(B, H, W), dev)
+        gl = grad_loss.to(torch.float32).contiguous()
+        grad_disp = torch.empty_like(disp)
+        want_edge = edge is not None and ctx.needs_input_grad[1]
+        grad_edge = torch.empty_like(edge) if want_edge else None
+        st = L.ctd_disparity_loss_bwd_f32(_ptr(disp), _ptr(edge), _ptr(gl), _ptr(grad_disp), _ptr(grad_edge), B, H, W,
+                                          _ptr(ws), ws.numel(), dev.index, _stream(dev))
+        _lib.check(st, "disparity_loss backward")
+        return grad_disp, grad_edge
+
+
+def disparity_loss(disp, edge=None):
+    return DisparityLossFunction.apply(disp, edge)
+
+
+class GeometricLossFunction(torch.autograd.Function):
+    """Symmetric two-view geometric loss (networks.ProjectionDepthSimilarityLoss.tforward, networks.py:500-503):
+    fwd(depth0 -> view 1) + fwd(depth1 -> view 0), each a mean of clamped |projected depth - sampled depth|."""
+
+    @staticmethod
+    def forward(ctx, depth0, depth1, ray, K, R0, t0, R1, t1, clamp):
+        ts = [_f32(x.contiguous(), n) for x, n in ((depth0, "depth0"), (depth1, "depth1"), (ray, "ray"), (K, "K"),
+                                                   (R0, "R0"), (t0, "t0"), (R1, "R1"), (t1, "t1"))]
+        depth0, depth1, ray, K, R0, t0, R1, t1 = ts
+        dev = _same_device(*ts)
+        if depth0.dim() != 4 or depth0.shape[1] != 1 or depth0.shape != depth1.shape:
+            raise RuntimeError("geometric_loss expects depth0, depth1 [B,1,H,W]")
+        B, _, H, W = depth0.shape
+        if ray.numel() != H * W * 3 or K.numel() != 9 or R0.numel() != B * 9 or R1.numel() != B * 9 or \
+                t0.numel() != B * 3 or t1.numel() != B * 3:
+            raise RuntimeError("geometric_loss: ray [H*W,3], K [3,3], R [B,3,3], t [B,3] expected")
+        L = _lib.lib()
+        ws = _workspace(L.ctd_geometric_workspace_bytes(B, H, W), dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        c = float(clamp)
+        st = L.ctd_geometric_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1),
+                                     _ptr(loss), 0, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+        _lib.check(st, "geometric_loss")
+        st = L.ctd_geometric_fwd_f32(_ptr(depth1), _ptr(depth0), _ptr(ray), _ptr(K), _ptr(R1), _ptr(t1), _ptr(R0), _ptr(t0),
+                                     _ptr(loss), 1, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+        _lib.check(st, "geometric_loss")
+        ctx.save_for_backward(depth0, depth1, ray, K, R0, t0, R1, t1)
+        ctx.clamp = c
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        depth0, depth1, ray, K, R0, t0, R1, t1 = ctx.saved_tensors
+        B, _, H, W = depth0.shape
+        dev = depth0.device
+        L = _lib.lib()
+        gl = grad_loss.to(torch.float32).contiguous()
+        g0 = torch.zeros_like(depth0)          # both receive bilinear scatter (atomics) from the other direction
+        g1 = torch.zeros_like(depth1)
+        st = L.ctd_geometric_bwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1),
+                                     _ptr(gl), _ptr(g0), 1, _ptr(g1), B, H, W, ctx.clamp, dev.index, _stream(dev))
+        _lib.check(st, "geometric_loss backward")
+        st = L.ctd_geometric_bwd_f32(_ptr(depth1), _ptr(depth0), _ptr(ray), _ptr(K), _ptr(R1), _ptr(t1), _ptr(R0), _ptr(t0),
+                                     _ptr(gl), _ptr(g1), 1, _ptr(g0), B, H, W, ctx.clamp, dev.index, _stream(dev))
+        _lib.check(st, "geometric_loss backward")
+        return g0, g1, None, None, None, None, None, None, None
+
+
+def geometric_loss(depth0, depth1, ray, K, R0, t0, R1, t1, clamp=-1):
+    return GeometricLossFunction.apply(depth0, depth1, ray, K, R0, t0, R1, t1, clamp)

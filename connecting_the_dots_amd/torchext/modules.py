@@ -37,3 +37,86 @@ class LCN(torch.nn.Module):
 
     def forward(self, data):
         return lcn(data.contiguous(), self.radius, self.epsilon)  # noqa: F405
+
+
+class RectifiedPatternSimilarityLoss(torch.nn.Module):
+    """Photometric loss of the reference (`networks.RectifiedPatternSimilarityLoss`, model/networks.py:340-378),
+    same constructor and call signature: warp the (channel-averaged) reference pattern by the predicted
+    disparity along u, compare with the image through the block photometric loss (block 9), and return
+    `((mask * diff).sum() / mask.sum(), pattern_proj)` with `mask = std` (or ones).
+
+    The warp is `grid_sample(bilinear, border)` exactly as the reference calls it today (normalised with W-1 /
+    H-1 but sampled with align_corners=False -- SURVEY 7.3-6); the block loss and its gradient are the HIP
+    kernels of photometric.hip.  Under data parallelism reduce numerator and denominator separately
+    (`connecting_the_dots_amd.sharding.reduce_ratio`)."""
+
+    def __init__(self, im_height, im_width, pattern, loss_type='census_sad', loss_eps=0.5):
+        super().__init__()
+        self.im_height = im_height
+        self.im_width = im_width
+        self.pattern = pattern.mean(dim=1, keepdim=True).contiguous()
+        u = torch.arange(im_width, dtype=torch.float32).view(1, 1, -1).expand(1, im_height, -1)
+        v = torch.arange(im_height, dtype=torch.float32).view(1, -1, 1).expand(1, -1, im_width)
+        self.u0, self.v0 = u.contiguous(), v.contiguous()
+        self.loss_type = loss_type
+        self.loss_eps = loss_eps
+
+    def terms(self, disp0, im, std=None):
+        """(numerator, denominator, pattern_proj) of the masked mean, for cross-rank reduction."""
+        dev = disp0.device
+        self.pattern, self.u0, self.v0 = self.pattern.to(dev), self.u0.to(dev), self.v0.to(dev)
+        B = disp0.shape[0]
+        u1 = self.u0 - disp0.contiguous().view(B, self.im_height, self.im_width)
+        gx = 2 * (u1 / (self.im_width - 1) - 0.5)
+        gy = (2 * (self.v0 / (self.im_height - 1) - 0.5)).expand(B, -1, -1)
+        grid = torch.stack((gx, gy), dim=3)
+        pattern = self.pattern.expand(B, *self.pattern.shape[1:])
+        pattern_proj = torch.nn.functional.grid_sample(pattern, grid, padding_mode='border', align_corners=False)
+        mask = torch.ones_like(im)
+        if std is not None:
+            mask = mask * std
+        diff = photometric_loss(pattern_proj.contiguous(), im.contiguous(), 9, self.loss_type, self.loss_eps)  # noqa: F405
+        return (mask * diff).sum(), mask.sum(), pattern_proj
+
+    def forward(self, disp0, im, std=None):
+        num, den, pattern_proj = self.terms(disp0, im, std)
+        return num / den, pattern_proj
+
+
+class DispToDepth(torch.nn.Module):
+    """`networks.DispToDepth(focal_length, baseline)` (model/networks.py:313-321), one fused kernel each way."""
+
+    def __init__(self, focal_length, baseline):
+        super().__init__()
+        self.baseline_focal_length = baseline * focal_length
+
+    def forward(self, disp):
+        return disp_to_depth(disp, self.baseline_focal_length)  # noqa: F405
+
+
+class DisparityLoss(torch.nn.Module):
+    """`networks.DisparityLoss()` (model/networks.py:380-412): Sobel + Laplace-mixture NLL (with `edge`) or
+    mean clamped gradient magnitude (without), fused forward and backward."""
+
+    def forward(self, disp, edge=None):
+        return disparity_loss(disp, edge)  # noqa: F405
+
+
+class ProjectionDepthSimilarityLoss(torch.nn.Module):
+    """`networks.ProjectionDepthSimilarityLoss(K, Ki, im_height, im_width, clamp=-1)` (model/networks.py:416-503),
+    same constructor and call signature `(depth0, depth1, R0, t0, R1, t1) -> scalar`."""
+
+    def __init__(self, K, Ki, im_height, im_width, clamp=-1):
+        super().__init__()
+        self.K = K.reshape(3, 3).to(torch.float32).contiguous()
+        self.im_height, self.im_width, self.clamp = im_height, im_width, clamp
+        # rays in float64 then float32, as the reference builds them with numpy (networks.py:428-434)
+        u = torch.arange(im_width, dtype=torch.float64).view(1, -1).expand(im_height, -1)
+        v = torch.arange(im_height, dtype=torch.float64).view(-1, 1).expand(-1, im_width)
+        uv1 = torch.stack((u, v, torch.ones_like(u)), dim=2).reshape(-1, 3)
+        self.ray = (uv1 @ Ki.reshape(3, 3).to(torch.float64).cpu().T).to(torch.float32).contiguous()
+
+    def forward(self, depth0, depth1, R0, t0, R1, t1):
+        dev = depth0.device
+        self.K, self.ray = self.K.to(dev), self.ray.to(dev)
+        return geometric_loss(depth0, depth1, self.ray, self.K, R0, t0, R1, t1, self.clamp)  # noqa: F405

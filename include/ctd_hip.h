@@ -17,7 +17,8 @@
  *     launched on the legacy default stream with no device guard (common_cuda.h:168);
  *   - return value: 0 on success, otherwise a ctd_status code (never exit(), unlike
  *     common_cuda.h:11-20); ctd_status_string() names it;
- *   - kernels are deterministic: no floating-point atomics anywhere.
+ *   - kernels are deterministic (no floating-point atomics) except ctd_geometric_bwd_f32, whose
+ *     bilinear scatter into grad_depth1 uses float atomics like ATen's grid_sample backward.
  */
 #ifndef CTD_HIP_H
 #define CTD_HIP_H
@@ -147,6 +148,52 @@ int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_st
  * -------------------------------------------------------------------------------------- */
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
                 float eps, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * DispToDepth.tforward, model/networks.py:313-321, and its backward.
+ *   depth = (baseline*focal) / (relu(disp) + 1e-12)
+ * -------------------------------------------------------------------------------------- */
+int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float baseline_focal,
+                              int device, void* stream);
+int ctd_disp_to_depth_bwd_f32(const float* disp, const float* grad_depth, float* grad_disp, long n,
+                              float baseline_focal, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Edge-aware disparity loss: SobelFilter (5x5, replicate pad) + DisparityLoss.tforward,
+ * model/networks.py:380-412, 537-565, fused.
+ *   disp [B][1][H][W], edge [B][1][H][W] or NULL  ->  loss[0] (device scalar, mean over B*H*W)
+ *   with edge   : mean(-log(clamp((1-e)/b0*exp(-g/b0) + e/b1*exp(-g/b1), 1e-4)))
+ *   without edge: mean(clamp(g, 0, 1)),   g = sqrt(gx^2 + gy^2 + 1e-8)
+ * Backward: grad_loss is a device scalar; grad_disp always written, grad_edge optional (NULL).
+ * Workspace: ctd_disparity_loss_workspace_bytes() bytes, shared layout for both directions.
+ * -------------------------------------------------------------------------------------- */
+size_t ctd_disparity_loss_workspace_bytes(int B, int H, int W);
+int ctd_disparity_loss_fwd_f32(const float* disp, const float* edge, float* loss, int B, int H, int W,
+                               void* workspace, size_t workspace_bytes, int device, void* stream);
+int ctd_disparity_loss_bwd_f32(const float* disp, const float* edge, const float* grad_loss,
+                               float* grad_disp, float* grad_edge, int B, int H, int W,
+                               void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Two-view geometric loss, ONE direction: ProjectionDepthSimilarityLoss.fwd,
+ * model/networks.py:483-498 (unproject depth0 along `ray`, rigid transform by (R0,t0) then
+ * (R1,t1), project with K, bilinear border-mode sample of depth1, mean clamped |d - sample|).
+ *   depth0, depth1 [B][1][H][W]; ray [H*W][3] = [u v 1] @ Ki^T (networks.py:428-434);
+ *   K [3][3]; R0, R1 [B][3][3]; t0, t1 [B][3]  (all device, f32);  clamp <= 0 disables clamping
+ *   loss[0] = (accumulate ? loss[0] : 0) + mean            (the module sums both directions)
+ * Backward: grad_depth0 = (accumulate0 ? grad_depth0 : 0) + d/d depth0; grad_depth1 is
+ * ACCUMULATED with float atomics (caller zero-fills once per backward).
+ * -------------------------------------------------------------------------------------- */
+size_t ctd_geometric_workspace_bytes(int B, int H, int W);
+int ctd_geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K,
+                          const float* R0, const float* t0, const float* R1, const float* t1,
+                          float* loss, int accumulate, int B, int H, int W, float clamp,
+                          void* workspace, size_t workspace_bytes, int device, void* stream);
+int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K,
+                          const float* R0, const float* t0, const float* R1, const float* t1,
+                          const float* grad_loss, float* grad_depth0, int accumulate0,
+                          float* grad_depth1, int B, int H, int W, float clamp, int device,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,9 @@ def test_python_surface_mirrors_reference_names():
     for name in ("xcorrvol", "XCorrVolFunction", "photometric_loss", "PhotometricLossFunction",
                  "photometric_loss_pytorch", "CoordConv2d"):
         assert hasattr(te, name), name
-    for name in ("xcorrvol_batch", "xcorrvol_argmax", "argmax_disp", "lcn", "LCN", "costvol"):
+    for name in ("xcorrvol_batch", "xcorrvol_argmax", "argmax_disp", "lcn", "LCN", "costvol", "disp_to_depth",
+                 "disparity_loss", "geometric_loss", "DispToDepth", "DisparityLoss", "ProjectionDepthSimilarityLoss",
+                 "RectifiedPatternSimilarityLoss"):
         assert hasattr(te, name), name
 
 
