@@ -362,10 +362,10 @@ constexpr int kWCols = 4;                     // product columns per lane
 #endif
 constexpr int kWND = CTD_WND;                 // disparities per lane (1 or 2)
 #ifndef CTD_WWAVES
-#define CTD_WWAVES 4
+#define CTD_WWAVES 8
 #endif
 #ifndef CTD_WROWS
-#define CTD_WROWS 2
+#define CTD_WROWS 3
 #endif
 #ifndef CTD_WBUFS
 #define CTD_WBUFS 3
