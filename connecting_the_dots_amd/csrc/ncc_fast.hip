@@ -27,6 +27,8 @@
 //     so the main kernels never subtract; one constant per image also keeps the
 //     reference's exact ties along d at the left border exact (same operands, same order).
 // Window means / deviations (ma, sa, mb, sb) come from the same separable f64 pre-pass.
+#include <type_traits>
+
 #include "ctd_internal.h"
 
 #ifndef CTD_ABLATE2
@@ -407,20 +409,27 @@ __device__ inline void lds_read4(const float* arr, int lane, float (&o)[4]) {
 }
 
 // out[i] = prev_lane(sp[i]) + own + next_lane(pn[i]) for the lane's 4 columns: 8 v_add_f32_dpp.
+// Every DPP add accumulates INTO a register preset to `own`: a lane whose shifted source does not exist
+// (lane 0 for wave_shr, lane 63 for wave_shl) is skipped by the hardware rather than fed a zero, so its
+// destination must already hold the right value (= a zero contribution from the missing neighbour).
 // One s_nop 1 covers the VALU-write -> DPP-read hazard of the operands (2 wait states).
 __device__ inline void window_combine4(const float (&sp)[4], float own, const float (&pn)[4], float (&o)[4]) {
+  o[0] = own;
+  o[1] = own;
+  o[2] = own;
+  o[3] = own;
   asm volatile(
       "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %1, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %2, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %3, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %0, %9, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %1, %10, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %2, %11, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %3, %12, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(own), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]));
+      "v_add_f32_dpp %0, %4, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %5, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %8, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %9, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %10, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %11, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
+      : "+&v"(o[0]), "+&v"(o[1]), "+&v"(o[2]), "+&v"(o[3])   // early clobber: inputs equal to `own` must not share a register
+      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]));
 }
 
 template <int BS, bool ACCUM, bool VEC4, int WAVE>
@@ -691,6 +700,298 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 #undef CTD_WCASE
 }
 
+// ------------------------------------------------------------------------------------
+// TILE-256 kernel (bs == 9, W % 4 == 0): the production kernel.
+// Same consumer pipeline as the wide kernel, but a wavefront's 64 lanes own exactly 256
+// OUTPUT columns (1 KB-aligned 16-byte stores, every lane valid, W = 512 is two tiles with
+// no leftover columns).  The two halo quads a tile needs (4 product columns left of lane 0,
+// 4 right of lane 63) are computed by the LOADER wavefront: its lanes hold, per consumer
+// wave and disparity, the vertical ring of the halo quad and publish its suffix / prefix
+// sums into the staged row, one chunk ahead of the consumers and under the same barrier.
+// Volume stores that are not 128-byte aligned cost ~25 % of HBM write bandwidth
+// (tools/ubench_store.hip), and per-CU operand staging is limited to ~10 B/clk
+// (tools/ubench_struct.hip), hence 16 disparities per workgroup.
+// ------------------------------------------------------------------------------------
+constexpr int kTWaves = 8;                     // consumer wavefronts per workgroup
+constexpr int kTND = 2;                        // disparities per lane
+constexpr int kTDG = kTWaves * kTND;           // 16 disparities per workgroup
+constexpr int kTTile = 256;                    // output columns per workgroup
+constexpr int kTA = kTTile + 8;                // frame-side array: 4 halo columns either side
+static_assert(kTA + kTDG - 1 < 280, "pattern span must fit its padded array");
+constexpr int kTSpanPad = 280;
+constexpr int kTHalo = kTWaves * kTND * 2 * 4; // [wave][j][side][4] halo sums
+constexpr int kTPack = 3 * kTA + 3 * kTSpanPad + kTHalo;   // 1760 floats per staged row
+#ifndef CTD_TROWS
+#define CTD_TROWS 3
+#endif
+#ifndef CTD_TBUFS
+#define CTD_TBUFS 3
+#endif
+constexpr int kTRows = CTD_TROWS;
+constexpr int kTBufs = CTD_TBUFS;
+constexpr int kTDmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
+constexpr int kTOffB = 3 * kTA, kTOffH = 3 * kTA + 3 * kTSpanPad;
+
+template <bool ACCUM, int WAVE>
+__device__ __forceinline__ void t256_consume(const float* lds, float* __restrict__ out, int f, int dg, int lane,
+                                             int w_lo, int h_lo, int h_hi, int r_begin, int n_iters, int H, int W,
+                                             int D) {
+  constexpr int BS = 9, TAIL = 4, STEP = lcm_ce(6, kTRows);
+  const long HW = (long)H * W;
+  const int d_base = dg * kTDG + WAVE * kTND;
+  const int c0 = w_lo + 4 * lane;
+  float* vol = out + (long)f * D * HW;
+  const bool lane_out = c0 < W;
+  const float nf = (float)(BS * BS);
+  float P[kTND][4][2], T[kTND][4][6];
+#pragma unroll
+  for (int j = 0; j < kTND; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      P[j][i][0] = P[j][i][1] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) T[j][i][k] = 0.f;
+    }
+  struct RowOps {
+    float a[4], ma[4], sa[4];
+    float b[kTND][4], mb[kTND][4], sb[kTND][4];
+  };
+  constexpr int kOff0 = (kTDG - 1) - WAVE * kTND;                  // span slot offset of disparity j = 0
+  auto load_row = [&](const float* pk) {
+    RowOps o;
+    lds_read4<0>(pk, lane + 1, o.a);                               // slot 4*(lane+1): own quad after the left halo
+    lds_read4<0>(pk + kTA, lane + 1, o.ma);
+    lds_read4<0>(pk + 2 * kTA, lane + 1, o.sa);
+    lds_read4<kOff0>(pk + kTOffB, lane + 1, o.b[0]);
+    lds_read4<kOff0>(pk + kTOffB + kTSpanPad, lane + 1, o.mb[0]);
+    lds_read4<kOff0>(pk + kTOffB + 2 * kTSpanPad, lane + 1, o.sb[0]);
+    lds_read4<kOff0 - 1>(pk + kTOffB, lane + 1, o.b[1]);
+    lds_read4<kOff0 - 1>(pk + kTOffB + kTSpanPad, lane + 1, o.mb[1]);
+    lds_read4<kOff0 - 1>(pk + kTOffB + 2 * kTSpanPad, lane + 1, o.sb[1]);
+    return o;
+  };
+  static_assert(kTND == 2, "two disparities per lane");
+  // halo sums: lane 0 takes the left quad's suffix sums, lane 63 the right quad's prefix sums, others zero
+  const int halo_side = lane == 63 ? 1 : 0;
+  // applied as a multiplicative mask: hipcc 7.2 miscompiles the select form `halo_lane ? hq[i] : 0.f` here
+  // (it zeroes the value for every lane < 63, lane 0 included)
+  const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;
+
+  wg_barrier();                                                    // chunk 0 (operands + halos) is in LDS
+  int chunk = 0;
+  for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < STEP; ++u) {
+      const int r = r_begin + it * STEP + u;
+      const bool last_of_chunk = (u % kTRows) == kTRows - 1;
+      const float* pk = lds + ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack;
+      const RowOps cur = load_row(pk);
+      float nma[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nma[i] = -nf * cur.ma[i];
+      const int h = r - TAIL;
+      const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
+#pragma unroll
+      for (int j = 0; j < kTND; ++j) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = cur.a[i] * cur.b[j][i];
+          const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
+          P[j][i][u % 2] = p;
+          x[i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+          T[j][i][u % 6] = t3;
+        }
+        float pre[4], suf[4];
+        pre[0] = x[0];
+        pre[1] = pre[0] + x[1];
+        pre[2] = pre[1] + x[2];
+        pre[3] = pre[2] + x[3];
+        suf[3] = x[3];
+        suf[2] = suf[3] + x[2];
+        suf[1] = suf[2] + x[1];
+        suf[0] = suf[1] + x[0];
+        float s[4];
+        window_combine4(suf, pre[3], pre, s);                       // wave-edge lanes get 0 from the missing neighbour
+        float hq[4];
+        lds_read4<0>(pk + kTOffH + ((WAVE * kTND + j) * 2) * 4, halo_side, hq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = fmaf(halo_mask, hq[i], s[i]);
+        float val[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
+          const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
+          val[i] = cov * __builtin_amdgcn_rcpf(den);
+        }
+        const int d = d_base + j;
+#if CTD_ABLATE == 1
+        if (row_out && lane_out && d < D && val[0] == 123456.789f) {
+#else
+        if (row_out && lane_out && d < D) {
+#endif
+          float4* o = (float4*)(vol + (long)d * HW + (long)h * W + c0);
+          float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
+          if (ACCUM) {
+            const float4 old = *o;
+            v4.x += old.x; v4.y += old.y; v4.z += old.z; v4.w += old.w;
+          }
+          *o = v4;
+        }
+      }
+      if (last_of_chunk) {
+        wait_lgkmcnt0();
+        wg_barrier();
+        ++chunk;
+      }
+    }
+  }
+}
+
+template <bool ACCUM>
+__global__ __launch_bounds__(64 * (kTWaves + 1)) void ncc_fast_t256_kernel(
+    const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
+    const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1,
+    int xoff) {
+  constexpr int HALF = 4, TAIL = 4, STEP = lcm_ce(6, kTRows), CPI = STEP / kTRows;   // chunks per outer iteration
+  extern __shared__ float lds[];               // [kTBufs][kTRows][kTPack]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
+  const int w_lo = blockIdx.x * kTTile;
+  const int h_lo = blockIdx.y * band_rows;
+  const int h_hi = min(h_lo + band_rows, H);
+  const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
+  const int n_rows = r_end - r_begin + 1;
+  const int n_iters = (n_rows + STEP - 1) / STEP;
+  const int n_chunks = n_iters * CPI;
+
+  if (wave == kTWaves) {
+    // ------------------------------ loader + halo wavefront ------------------------------
+    const float* a_img = ac + ((long)f * C + c) * H * Wp + 4;      // +4: column c lives at c + 4
+    const float* m0i = m0 + ((long)f * C + c) * H * Wp + 4;
+    const float* v0i = v0 + ((long)f * C + c) * H * Wp + 4;
+    const float* b_img = bc + (long)f * st1_frame_stride + (long)c * H * W1;
+    const float* m1i = m1 + (long)f * st1_frame_stride + (long)c * H * W1;
+    const float* v1i = v1 + (long)f * st1_frame_stride + (long)c * H * W1;
+    const int c_lo = w_lo - 4;
+    const int xb = c_lo - (dg * kTDG + kTDG - 1);                  // unclamped pattern column of span slot 0
+    const int aq0 = min(c_lo + 4 * lane, Wp - 8), aq1 = min(c_lo + 256 + 4 * lane, Wp - 8);
+    const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
+    const bool a_tail = 256 + 4 * lane < kTA, s_tail = 256 + 4 * lane < kTSpanPad;
+    auto issue_chunk = [&](int chunk) {
+      float* buf = lds + (chunk % kTBufs) * (kTRows * kTPack);
+#pragma unroll
+      for (int s = 0; s < kTRows; ++s) {
+        const int r = r_begin + chunk * kTRows + s;
+        const int rc = clampi(r, 0, H - 1);
+        const int hs = clampi(r - TAIL, 0, H - 1);
+        float* pk = buf + s * kTPack;
+        dma_quad(a_img + (long)rc * Wp + aq0, pk);
+        dma_quad(m0i + (long)hs * Wp + aq0, pk + kTA);
+        dma_quad(v0i + (long)hs * Wp + aq0, pk + 2 * kTA);
+        dma_quad(b_img + (long)rc * W1 + sq0, pk + kTOffB);
+        dma_quad(m1i + (long)hs * W1 + sq0, pk + kTOffB + kTSpanPad);
+        dma_quad(v1i + (long)hs * W1 + sq0, pk + kTOffB + 2 * kTSpanPad);
+        if (a_tail) {
+          dma_quad(a_img + (long)rc * Wp + aq1, pk + 256);
+          dma_quad(m0i + (long)hs * Wp + aq1, pk + kTA + 256);
+          dma_quad(v0i + (long)hs * Wp + aq1, pk + 2 * kTA + 256);
+        }
+        if (s_tail) {
+          dma_quad(b_img + (long)rc * W1 + sq1, pk + kTOffB + 256);
+          dma_quad(m1i + (long)hs * W1 + sq1, pk + kTOffB + kTSpanPad + 256);
+          dma_quad(v1i + (long)hs * W1 + sq1, pk + kTOffB + 2 * kTSpanPad + 256);
+        }
+      }
+    };
+    // halo job of this lane: consumer wave cw, disparity j, side (0 = quad left of the tile, 1 = right of it)
+    const int cw = lane >> 2, hj = (lane >> 1) & 1, side = lane & 1;
+    const bool has_job = lane < 4 * kTWaves;
+    const int a_slot = side ? (kTA - 4) : 0;
+    const int b_slot = a_slot + (kTDG - 1) - (cw * kTND + hj);
+    float hP[4][2], hT[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hP[i][0] = hP[i][1] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) hT[i][k] = 0.f;
+    }
+    // vertical ring update of the halo quad for the rows of one chunk; UB = ring phase of its first row
+    auto halo_chunk = [&](int chunk, auto ub_tag) {
+      constexpr int UB = decltype(ub_tag)::value;
+      const float* buf = lds + (chunk % kTBufs) * (kTRows * kTPack);
+#pragma unroll
+      for (int s = 0; s < kTRows; ++s) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int u = (UB + s) % 6;
+        const float* pk = buf + s * kTPack;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = has_job ? pk[a_slot + i] * pk[kTOffB + b_slot + i] : 0.f;
+          const float t3 = p + hP[i][(u + 1) % 2] + hP[i][u % 2];
+          hP[i][u % 2] = p;
+          x[i] = t3 + hT[i][(u + 3) % 6] + hT[i][u % 6];
+          hT[i][u % 6] = t3;
+        }
+        float o4[4];
+        if (side) {                                                // prefix sums: columns 0..i of the right quad
+          o4[0] = x[0]; o4[1] = o4[0] + x[1]; o4[2] = o4[1] + x[2]; o4[3] = o4[2] + x[3];
+        } else {                                                   // suffix sums: columns i..3 of the left quad
+          o4[3] = x[3]; o4[2] = o4[3] + x[2]; o4[1] = o4[2] + x[1]; o4[0] = o4[1] + x[0];
+        }
+        if (has_job) {
+          float* hq = const_cast<float*>(pk) + kTOffH + lane * 4;  // lane == ((cw*kTND + hj)*2 + side)
+          hq[0] = o4[0]; hq[1] = o4[1]; hq[2] = o4[2]; hq[3] = o4[3];
+        }
+      }
+    };
+    constexpr int L = kTRows * kTDmaPerRow;
+    static_assert(L * (kTBufs - 2) < 64, "in-flight DMA count must fit vmcnt");
+#pragma unroll
+    for (int k = 0; k < kTBufs - 1; ++k)
+      if (k < n_chunks) issue_chunk(k);
+    if (n_chunks >= kTBufs - 1) wait_vmcnt<L*(kTBufs - 2)>(); else wait_vmcnt<0>();
+    halo_chunk(0, std::integral_constant<int, 0>{});
+    wait_lgkmcnt0();
+    wg_barrier();
+    for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+      for (int cc = 0; cc < CPI; ++cc) {
+        const int ch = it * CPI + cc;
+        const int nxt = ch + kTBufs - 1;
+        if (nxt < n_chunks) {
+          issue_chunk(nxt);
+          wait_vmcnt<L*(kTBufs - 2)>();                       // chunk ch+1 has landed
+        } else {
+          wait_vmcnt<0>();
+        }
+        if (ch + 1 < n_chunks) {
+          if (cc == 0) halo_chunk(ch + 1, std::integral_constant<int, (1 * kTRows) % 6>{});
+          else if (cc == 1) halo_chunk(ch + 1, std::integral_constant<int, (2 * kTRows) % 6>{});
+          else if (cc == 2) halo_chunk(ch + 1, std::integral_constant<int, (3 * kTRows) % 6>{});
+          else if (cc == 3) halo_chunk(ch + 1, std::integral_constant<int, (4 * kTRows) % 6>{});
+          else if (cc == 4) halo_chunk(ch + 1, std::integral_constant<int, (5 * kTRows) % 6>{});
+          else halo_chunk(ch + 1, std::integral_constant<int, (6 * kTRows) % 6>{});
+        }
+        wait_lgkmcnt0();
+        wg_barrier();
+      }
+    }
+    return;
+  }
+
+#define CTD_TCASE(WV) \
+  case WV: t256_consume<ACCUM, WV>(lds, out, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+  switch (wave) {
+    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5) CTD_TCASE(6) CTD_TCASE(7)
+    default: break;
+  }
+#undef CTD_TCASE
+}
+
 struct FastWorkspace {
   float *ac, *m0, *v0;        // centred frames, their window mean (centred) / deviation planes   [N*C][H][W]
   float *bc, *m1, *v1;        // same for the pattern, per UNCLAMPED window-centre column          [..][H][W1]
@@ -752,6 +1053,26 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
                        int W, int D, const FastWorkspace& ws, hipStream_t stream) {
   constexpr int WOUT = 64 - (BS - 1);
   const long st1_stride = in1_frame_stride ? (long)C * H * ws.W1 : 0;
+  if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0) {
+    // production path: 256-column tiles, every store a full aligned KB
+    const int n_dg = ceil_div(D, kTDG);
+    const int n_tiles = ceil_div(W, kTTile);
+    const int bands = pick_bands((long)n_tiles * frames * n_dg, H, BS);
+    const int band_rows = ceil_div(H, bands);
+    dim3 grid(n_tiles, ceil_div(H, band_rows), frames * n_dg), block(64 * (kTWaves + 1));
+    const size_t lds = sizeof(float) * kTBufs * kTRows * kTPack;
+    for (int c = 0; c < C; ++c) {
+      auto kern = c == 0 ? ncc_fast_t256_kernel<false> : ncc_fast_t256_kernel<true>;
+      if (lds > 64 * 1024)
+        CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      timing_begin(stream);
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C,
+                         c, H, W, D, band_rows, n_dg, ws.Wp, ws.W1, ws.xoff);
+      timing_end(stream, W);
+      CTD_LAUNCH_CHECK();
+    }
+    return CTD_OK;
+  }
   // column split: full 248-column wide tiles (plus one more when the remainder is large),
   // the rest in 64-(BS-1)-column narrow tiles
   int n_wide = W / kWOut;
