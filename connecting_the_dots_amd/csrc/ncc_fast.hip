@@ -408,6 +408,20 @@ __device__ inline void lds_read4(const float* arr, int lane, float (&o)[4]) {
   }
 }
 
+// Five floats starting OFF slots after the lane's own quad, from two aligned quads: element k of `lo5` is
+// slot OFF + k.  Two adjacent disparities of a lane (span offsets OFF+1 and OFF) read the same two quads.
+template <int OFF>
+__device__ inline void lds_read5(const float* arr, int lane, float (&o)[5]) {
+  constexpr int Q = OFF / 4, S = OFF % 4;
+  f32x4 A = *(const f32x4*)(arr + 4 * (lane + Q));
+  f32x4 B = *(const f32x4*)(arr + 4 * (lane + Q + 1));
+  asm("" : "+v"(A));
+  asm("" : "+v"(B));
+  const float e[8] = {A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3]};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) o[k] = e[S + k];
+}
+
 // out[i] = prev_lane(sp[i]) + own + next_lane(pn[i]) for the lane's 4 columns: 8 v_add_f32_dpp.
 // Every DPP add accumulates INTO a register preset to `own`: a lane whose shifted source does not exist
 // (lane 0 for wave_shr, lane 63 for wave_shl) is skipped by the hardware rather than fed a zero, so its
@@ -712,13 +726,16 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 // (tools/ubench_store.hip), and per-CU operand staging is limited to ~10 B/clk
 // (tools/ubench_struct.hip), hence 16 disparities per workgroup.
 // ------------------------------------------------------------------------------------
-constexpr int kTWaves = 8;                     // consumer wavefronts per workgroup
+#ifndef CTD_TWAVES
+#define CTD_TWAVES 6
+#endif
+constexpr int kTWaves = CTD_TWAVES;            // consumer wavefronts per workgroup (6: two 7-wave workgroups per CU at 128 VGPRs)
 constexpr int kTND = 2;                        // disparities per lane
 constexpr int kTDG = kTWaves * kTND;           // 16 disparities per workgroup
 constexpr int kTTile = 256;                    // output columns per workgroup
 constexpr int kTA = kTTile + 8;                // frame-side array: 4 halo columns either side
-static_assert(kTA + kTDG - 1 < 280, "pattern span must fit its padded array");
-constexpr int kTSpanPad = 280;
+constexpr int kTSpanPad = (kTA + kTDG - 1 + 1 + 3) / 4 * 4;   // multiple of 4, > span
+static_assert(kTA + kTDG - 1 < kTSpanPad, "pattern span must fit its padded array");
 constexpr int kTHalo = kTWaves * kTND * 2 * 4; // [wave][j][side][4] halo sums
 constexpr int kTPack = 3 * kTA + 3 * kTSpanPad + kTHalo;   // 1760 floats per staged row
 #ifndef CTD_TROWS
@@ -762,12 +779,18 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
     lds_read4<0>(pk, lane + 1, o.a);                               // slot 4*(lane+1): own quad after the left halo
     lds_read4<0>(pk + kTA, lane + 1, o.ma);
     lds_read4<0>(pk + 2 * kTA, lane + 1, o.sa);
-    lds_read4<kOff0>(pk + kTOffB, lane + 1, o.b[0]);
-    lds_read4<kOff0>(pk + kTOffB + kTSpanPad, lane + 1, o.mb[0]);
-    lds_read4<kOff0>(pk + kTOffB + 2 * kTSpanPad, lane + 1, o.sb[0]);
-    lds_read4<kOff0 - 1>(pk + kTOffB, lane + 1, o.b[1]);
-    lds_read4<kOff0 - 1>(pk + kTOffB + kTSpanPad, lane + 1, o.mb[1]);
-    lds_read4<kOff0 - 1>(pk + kTOffB + 2 * kTSpanPad, lane + 1, o.sb[1]);
+    // disparity j = 1 sits one span slot below j = 0: both quads of values come out of the same two
+    // ds_read_b128 per array (slot offsets kOff0 - 1 .. kOff0 + 3)
+    float e[5];
+    lds_read5<kOff0 - 1>(pk + kTOffB, lane + 1, e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.b[1][i] = e[i]; o.b[0][i] = e[i + 1]; }
+    lds_read5<kOff0 - 1>(pk + kTOffB + kTSpanPad, lane + 1, e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.mb[1][i] = e[i]; o.mb[0][i] = e[i + 1]; }
+    lds_read5<kOff0 - 1>(pk + kTOffB + 2 * kTSpanPad, lane + 1, e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.sb[1][i] = e[i]; o.sb[0][i] = e[i + 1]; }
     return o;
   };
   static_assert(kTND == 2, "two disparities per lane");
@@ -849,7 +872,7 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
 }
 
 template <bool ACCUM>
-__global__ __launch_bounds__(64 * (kTWaves + 1)) void ncc_fast_t256_kernel(
+__global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
     float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1,
@@ -984,9 +1007,12 @@ __global__ __launch_bounds__(64 * (kTWaves + 1)) void ncc_fast_t256_kernel(
   }
 
 #define CTD_TCASE(WV) \
-  case WV: t256_consume<ACCUM, WV>(lds, out, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+  case WV: t256_consume<ACCUM, (WV < kTWaves ? WV : 0)>(lds, out, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
   switch (wave) {
-    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5) CTD_TCASE(6) CTD_TCASE(7)
+    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5)
+#if CTD_TWAVES > 6
+    CTD_TCASE(6) CTD_TCASE(7)
+#endif
     default: break;
   }
 #undef CTD_TCASE
