@@ -179,12 +179,12 @@ def main():
             "disparity_mae_vs_ref": parity_probe(te, device),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ncc_fast_wide_kernel" if args.algo == "fast" else "ncc_exact_kernel",
+                "kernel": "ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "avg_launch_ms": avg_ms.value, "launches": n_launch,
                 "algorithmic_bytes_per_launch": kernel_units * BYTES_PER_PIXDISP,
-                "traffic": measured_traffic("ncc_fast_wide_kernel" if args.algo == "fast" else "ncc_exact_kernel"),
+                "traffic": measured_traffic("ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel"),
             },
         }
         if not args.no_cpu_baseline:
