@@ -82,14 +82,57 @@ __device__ static float ncc_exact_point_lds(const float* sA, const float* sB, in
   return val;
 }
 
+// Same value, computed by a whole wavefront: lane t (and t + 64) owns tap t of the window, the per-tap terms
+// are formed in parallel and only the reference's tap-order accumulations run serially, fed by v_readlane.
+// Bit-identical to ncc_exact_point_lds (same operations on the same operands in the same order), but a
+// few hundred register-only instructions instead of a latency chain of ~650 dependent LDS reads.
+__device__ static float ncc_exact_point_wave(const float* sA, const float* sB, int bs, int span, int off, int lane) {
+  const int n = bs * bs;                                  // <= 128 taps (bs <= 11)
+  const float bs2 = (float)n;
+  const int t0 = lane, t1 = lane + 64;
+  const bool h0 = t0 < n, h1 = t1 < n;
+  const float a0 = h0 ? sA[t0] : 0.f, a1 = h1 ? sA[t1] : 0.f;
+  const float b0 = h0 ? sB[(t0 / bs) * span + (t0 % bs) + off] : 0.f;
+  const float b1 = h1 ? sB[(t1 / bs) * span + (t1 % bs) + off] : 0.f;
+  const float qa0 = a0 / bs2, qa1 = a1 / bs2, qb0 = b0 / bs2, qb1 = b1 / bs2;
+  float mu0 = 0.f, mu1 = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int l = t & 63;
+    const float xa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qa0 : qa1), l));
+    const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qb0 : qb1), l));
+    mu0 += xa;
+    mu1 += xb;
+  }
+  const float va0 = a0 - mu0, va1 = a1 - mu0, vb0 = b0 - mu1, vb1 = b1 - mu1;
+  const float pd0 = va0 * vb0, pd1 = va1 * vb1, pa0 = va0 * va0, pa1 = va1 * va1, pb0 = vb0 * vb0, pb1 = vb1 * vb1;
+  float dot = 0.f, s0 = 0.f, s1 = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int l = t & 63;
+    dot += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pd0 : pd1), l));
+    s0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pa0 : pa1), l));
+    s1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pb0 : pb1), l));
+  }
+  const float norm = (float)((double)sqrtf(s0 * s1) + 1e-8);
+  float val = 0.f;
+  val += dot / norm;
+  return val;
+}
+
 // Pass 1: one coalesced sweep over d, 4 adjacent pixels per thread (16-byte loads), branch-free tracking of
 // the best score / index and of the runner-up score.  Pixels whose runner-up is within eps of the best are
 // marked (idx = -1 - argmax) for pass 2; all others are final.
-template <bool VEC4>
-__global__ __launch_bounds__(256) void argmax_scan_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
+#ifndef CTD_SCAN_BATCH
+#define CTD_SCAN_BATCH 8
+#endif
+#ifndef CTD_SCAN_WAVES
+#define CTD_SCAN_WAVES 5
+#endif
+template <int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTD_SCAN_WAVES, 8))) void argmax_scan_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
                                                           float* __restrict__ best, int D, long HW, int W,
-                                                          int bs, float eps, long total_threads) {
-  constexpr int PX = VEC4 ? 4 : 1;
+                                                          int bs, float eps, long total_threads,
+                                                          unsigned* __restrict__ n_hard,
+                                                          int64_t* __restrict__ hard_list) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_threads) return;
   const long p0 = t * PX;                         // first pixel (flat over frames); HW % 4 == 0 when VEC4
@@ -102,21 +145,51 @@ __global__ __launch_bounds__(256) void argmax_scan_kernel(const float* __restric
   int i0[PX], dc[PX];
 #pragma unroll
   for (int k = 0; k < PX; ++k) { v0[k] = -INFINITY; v1[k] = -INFINITY; i0[k] = 0; dc[k] = w0 + k + (bs - 1 - bs / 2); }
-#pragma unroll 8
-  for (int d = 0; d < D; ++d) {
-    float x[PX];
-    if constexpr (VEC4) {
-      const float4 q = *(const float4*)(v + (long)d * HW);
-      x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-    } else {
-      x[0] = v[(long)d * HW];
-    }
+  // explicit batches of kBatch independent loads (the compiler otherwise waits for each plane before
+  // requesting the next); streamed once, so non-temporal
+  constexpr int kBatch = CTD_SCAN_BATCH;
+  const bool wave_masks = __any(dc[0] < D - 1);
+  for (int d0 = 0; d0 < D; d0 += kBatch) {
+    float x[kBatch][PX];
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-      const float y = d > dc[k] ? -INFINITY : x[k];
-      v1[k] = fmaxf(v1[k], fminf(v0[k], y));      // runner-up = second largest seen so far
-      i0[k] = y > v0[k] ? d : i0[k];              // strict >: first index wins ties
-      v0[k] = fmaxf(v0[k], y);
+    for (int u = 0; u < kBatch; ++u) {
+      const float* src = v + (long)min(d0 + u, D - 1) * HW;
+      if constexpr (PX == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 q = __builtin_nontemporal_load((const f4*)src);
+        x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+      } else if constexpr (PX == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 q = __builtin_nontemporal_load((const f2*)src);
+        x[u][0] = q.x; x[u][1] = q.y;
+      } else {
+        x[u][0] = __builtin_nontemporal_load(src);
+      }
+    }
+    // a wave whose columns all lie past D - 1 - (bs-1-bs/2) has no clamped run to mask (wave-uniform)
+    if (wave_masks || d0 + kBatch > D) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int d = d0 + u;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          const float y = (d > dc[k] || d >= D) ? -INFINITY : x[u][k];
+          v1[k] = __builtin_amdgcn_fmed3f(v0[k], v1[k], y);   // runner-up = second largest of {v0 >= v1, y}
+          i0[k] = y > v0[k] ? d : i0[k];                      // strict >: first index wins ties
+          v0[k] = fmaxf(v0[k], y);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          const float y = x[u][k];
+          v1[k] = __builtin_amdgcn_fmed3f(v0[k], v1[k], y);
+          i0[k] = y > v0[k] ? d0 + u : i0[k];
+          v0[k] = fmaxf(v0[k], y);
+        }
+      }
     }
   }
 #pragma unroll
@@ -124,80 +197,62 @@ __global__ __launch_bounds__(256) void argmax_scan_kernel(const float* __restric
     const bool hard = v1[k] >= v0[k] - eps;
     idx[p0 + k] = hard ? (int64_t)(-1 - i0[k]) : (int64_t)i0[k];
     if (best) best[p0 + k] = v0[k];
+    if (hard) hard_list[atomicAdd(n_hard, 1u)] = p0 + k;   // rare (a few pixels in 10^4): pass 2's work list
   }
 }
 
-// Pass 2: every wavefront visits chunks of 64 index slots.  A chunk with marked pixels is re-swept over d
-// with the same coalesced access as pass 1 (lane <-> pixel; per-lane strided reads of the volume would touch
-// one 4 KB page per lane and disparity) to collect each marked pixel's candidate set as a bit mask: scores
-// within eps of the pixel's best, the run of disparities whose window is clamped to column 0 counted once
-// (lowest d).  A pixel with a single candidate is final; otherwise the whole wave resolves it: the frame
-// window and the reachable pattern rows are staged in LDS, lane <-> disparity re-scores its candidates in
-// reference order, and a wave reduction picks the best exact score, lowest d first.
+// Pass 2: one wavefront per marked pixel of the work list.  Lane <-> disparity collects the pixel's candidate
+// set with one round of loads (scores within eps of the best; the run of disparities whose window is clamped
+// to column 0 counted once, lowest d); a single candidate is final, otherwise the frame window and the
+// reachable pattern rows are staged in LDS and the wave re-scores each candidate in reference order.
 constexpr int kMaskWords = 8;            // disparities per candidate mask = 512
 
 __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __restrict__ vol,
                                                              const float* __restrict__ in0,
                                                              const float* __restrict__ in1, long in1_frame_stride,
                                                              int64_t* __restrict__ idx, float* __restrict__ best,
-                                                             int D, int H, int W, int bs, float eps, long total) {
+                                                             int D, int H, int W, int bs, float eps,
+                                                             const unsigned* __restrict__ n_hard,
+                                                             const int64_t* __restrict__ hard_list) {
   extern __shared__ float lds_resolve[];
   const int lane = threadIdx.x & 63;
   const int half = bs / 2, span = bs + D - 1;
   float* sA = lds_resolve + (threadIdx.x >> 6) * (bs * bs + bs * span);   // per-wave staging area
   float* sB = sA + bs * bs;
   const long HW = (long)H * W;
-  // grid-stride over 256-pixel chunks (a few thousand workgroups instead of one tiny workgroup per chunk)
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p - lane < total; p += (long)gridDim.x * blockDim.x) {
-    const bool mine = p < total && idx[p] < 0;
-    unsigned long long todo = __ballot(mine);
-    if (!todo) continue;
-    const long pc = p < total ? p : total - 1;             // idle tail lanes shadow the last pixel
-    const long f = pc / HW, q = pc - f * HW;
-    const int w = (int)(q % W);
-    const float* v = vol + f * D * HW + q;
-    const int d_clamped = w + (bs - 1 - bs / 2);
-    const float m = mine ? v[(-1 - idx[pc]) * HW] : INFINITY;
-    unsigned long long mask[kMaskWords];
+  const unsigned count = *n_hard;
+  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+  for (unsigned item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < count; item += n_waves) {
+    const long pj = hard_list[item];                       // wave-uniform from here on
+    const long fj = pj / HW, qj = pj - fj * HW;
+    const int hj = (int)(qj / W), wj = (int)(qj - (long)hj * W);
+    const float* v = vol + fj * D * HW + qj;
+    const int d_clamped = wj + (bs - 1 - bs / 2);
+    const float m = v[(-1 - idx[pj]) * HW];
+    float x[kMaskWords];
 #pragma unroll
-    for (int k = 0; k < kMaskWords; ++k) mask[k] = 0ull;
+    for (int wd = 0; wd < kMaskWords; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
+    unsigned long long mask[kMaskWords];
     bool have_clamped = false;
-    int n_cand = 0, only = 0;
+    int n_cand = 0;
 #pragma unroll
     for (int wd = 0; wd < kMaskWords; ++wd) {
-      if (wd * 64 < D) {                                   // wave-uniform
-        unsigned long long bits = 0ull;
-        const int d_hi = min(D, wd * 64 + 64);
-        // 16 independent loads in flight per batch: a lone wave must not pay one HBM round trip per disparity
-        for (int d0 = wd * 64; d0 < d_hi; d0 += 16) {
-          float x[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) x[k] = v[(long)min(d0 + k, D - 1) * HW];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int d = d0 + k;
-            bool cand = d < d_hi && x[k] >= m - eps;
-            if (cand && d >= d_clamped) {
-              cand = !have_clamped;
-              have_clamped = true;
-            }
-            if (cand) { bits |= 1ull << (d & 63); ++n_cand; only = d; }
-          }
+      unsigned long long bits = __ballot(wd * 64 + lane < D && x[wd] >= m - eps);
+      const int c0 = d_clamped - wd * 64;                  // bits >= c0 belong to the clamped run
+      if (c0 < 64) {
+        const unsigned long long run = c0 <= 0 ? bits : bits & ~((1ull << c0) - 1ull);
+        bits &= ~run;
+        if (!have_clamped && run) {
+          bits |= run & (0ull - run);                      // lowest disparity of the run stands for all of it
+          have_clamped = true;
         }
-        mask[wd] = bits;
       }
+      mask[wd] = bits;
+      n_cand += __popcll(bits);
     }
-    if (mine && n_cand == 1) {                             // nothing to compare against
-      idx[p] = only;
-      if (best) best[p] = v[(long)only * HW];
-    }
-    todo = __ballot(mine && n_cand > 1);
-    while (todo) {
-      const int j = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const long pj = p - lane + j;                        // wave-uniform
-      const long fj = pj / HW, qj = pj - fj * HW;
-      const int hj = (int)(qj / W), wj = (int)(qj - (long)hj * W);
+    float eb = 0.f;
+    int ei = 0x7fffffff;
+    if (n_cand > 1) {
       const float* a = in0 + fj * HW;
       const float* b = in1 + fj * in1_frame_stride;
       for (int i = lane; i < bs * bs; i += 64) {
@@ -216,57 +271,61 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
         for (int k = 0; k < 8; ++k)
           if (i0 + 64 * k < bs * span) sB[i0 + 64 * k] = t[k];
       }
-      float eb = -INFINITY;
-      int ei = 0x7fffffff;
+    }
+    // candidates in ascending d: strict > keeps the lowest index on ties
+    bool first = true;
 #pragma unroll
-      for (int wd = 0; wd < kMaskWords; ++wd) {
-        if (wd * 64 < D) {
-          const unsigned lo = __shfl((unsigned)(mask[wd] & 0xffffffffull), j);
-          const unsigned hi = __shfl((unsigned)(mask[wd] >> 32), j);
-          const unsigned long long mj = ((unsigned long long)hi << 32) | lo;
-          if ((mj >> lane) & 1ull) {
-            const int d = wd * 64 + lane;
-#if CTD_RESOLVE_ABLATE >= 1
-            const float e = sA[lane % 7] + sB[d];
-#else
-            const float e = ncc_exact_point_lds(sA, sB, bs, span, (D - 1) - d);
-#endif
-            if (e > eb || (e == eb && d < ei)) { eb = e; ei = d; }
-          }
-        }
+    for (int wd = 0; wd < kMaskWords; ++wd) {
+      unsigned long long mj = mask[wd];
+      while (mj) {
+        const int d = wd * 64 + __ffsll((long long)mj) - 1;
+        mj &= mj - 1;
+        float e = 0.f;
+        if (n_cand > 1)
+          e = bs <= 11 ? ncc_exact_point_wave(sA, sB, bs, span, (D - 1) - d, lane)
+                       : ncc_exact_point_lds(sA, sB, bs, span, (D - 1) - d);
+        if (first || e > eb) { eb = e; ei = d; first = false; }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float oe = __shfl_xor(eb, off);
-        const int oi = __shfl_xor(ei, off);
-        if (oe > eb || (oe == eb && oi < ei)) { eb = oe; ei = oi; }
-      }
-      if (lane == 0) {
-        idx[pj] = ei;
-        if (best) best[pj] = vol[fj * D * HW + (long)ei * HW + qj];
-      }
+    }
+    if (lane == 0) {
+      idx[pj] = ei;
+      if (best) best[pj] = v[(long)ei * HW];
     }
   }
 }
 
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
-                      float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream) {
+                      float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
   if (D > kMaskWords * 64) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
   const long HW = (long)H * W;
+  // work list of marked pixels: a counter and room for every pixel (the volume kernel is done with the
+  // workspace by the time these kernels run on the same stream)
+  if (!workspace || workspace_bytes < 16 + sizeof(int64_t) * (size_t)total) return CTD_ERR_WORKSPACE;
+  unsigned* n_hard = (unsigned*)workspace;
+  int64_t* hard_list = (int64_t*)((char*)workspace + 16);
+  CTD_HIP_TRY(hipMemsetAsync(n_hard, 0, 16, stream));
   const bool vec4 = W % 4 == 0 && ((uintptr_t)vol % 16) == 0;
-  if (vec4)
-    hipLaunchKernelGGL(argmax_scan_kernel<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, vol,
-                       idx, best, D, HW, W, bs, eps, total / 4);
+  static const int px_env = getenv("CTD_SCAN_PX") ? atoi(getenv("CTD_SCAN_PX")) : 4;
+  static const int lds_env = getenv("CTD_SCAN_LDS") ? atoi(getenv("CTD_SCAN_LDS")) : 0;
+  const int px = vec4 ? px_env : 1;
+  if (px == 4)
+    hipLaunchKernelGGL(argmax_scan_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), lds_env, stream, vol,
+                       idx, best, D, HW, W, bs, eps, total / 4, n_hard, hard_list);
+  else if (px == 2)
+    hipLaunchKernelGGL(argmax_scan_kernel<2>, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), lds_env, stream, vol,
+                       idx, best, D, HW, W, bs, eps, total / 2, n_hard, hard_list);
   else
-    hipLaunchKernelGGL(argmax_scan_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, vol, idx,
-                       best, D, HW, W, bs, eps, total);
+    hipLaunchKernelGGL(argmax_scan_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), lds_env, stream, vol, idx,
+                       best, D, HW, W, bs, eps, total, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
+  if (eps < 0.f) return CTD_OK;                            // nothing is marked: plain argmax of the fast volume
   const size_t lds = sizeof(float) * 4 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
   if (lds > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   const long chunks = (total + 255) / 256;
-  hipLaunchKernelGGL(argmax_resolve_kernel, dim3((unsigned)(chunks < 2048 ? chunks : 2048)), dim3(256), lds, stream, vol, in0,
-                     in1, in1_frame_stride, idx, best, D, H, W, bs, eps, total);
+  hipLaunchKernelGGL(argmax_resolve_kernel, dim3((unsigned)(chunks < 1024 ? chunks : 1024)), dim3(256), lds, stream, vol,
+                     in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
