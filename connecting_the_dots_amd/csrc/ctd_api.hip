@@ -268,4 +268,51 @@ int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float*
                            H, W, clamp, (hipStream_t)stream);
 }
 
+int ctd_nn_f32(const float* in0, const float* in1, long n0, long n1, int64_t* out, int device, void* stream) {
+  if (n0 < 0 || n1 < 0) return CTD_ERR_INVALID_ARG;
+  if (n0 == 0) return CTD_OK;
+  if (!in0 || !out || (n1 > 0 && !in1)) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return nn_f32(in0, in1, n0, n1, out, (hipStream_t)stream);
+}
+
+int ctd_nn_f64(const double* in0, const double* in1, long n0, long n1, int64_t* out, int device, void* stream) {
+  if (n0 < 0 || n1 < 0) return CTD_ERR_INVALID_ARG;
+  if (n0 == 0) return CTD_OK;
+  if (!in0 || !out || (n1 > 0 && !in1)) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return nn_f64(in0, in1, n0, n1, out, (hipStream_t)stream);
+}
+
+int ctd_crosscheck(const int64_t* in0, const int64_t* in1, long n0, long n1, uint8_t* out, int device, void* stream) {
+  if (n0 < 0 || n1 < 0) return CTD_ERR_INVALID_ARG;
+  if (n0 == 0) return CTD_OK;
+  if (!in0 || !out || (n1 > 0 && !in1)) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return crosscheck_i64(in0, in1, n0, n1, out, (hipStream_t)stream);
+}
+
+int ctd_proj_nn_f32(const float* xyz0, const float* xyz1, const float* K, int B, int H, int W, int patch_size,
+                    int64_t* out, int device, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || patch_size < 0) return CTD_ERR_INVALID_ARG;
+  if (B == 0) return CTD_OK;
+  if (!xyz0 || !xyz1 || !K || !out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return proj_nn_f32(xyz0, xyz1, K, B, H, W, patch_size, out, (hipStream_t)stream);
+}
+
+int ctd_proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, int B, int H, int W, int patch_size,
+                    int64_t* out, int device, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || patch_size < 0) return CTD_ERR_INVALID_ARG;
+  if (B == 0) return CTD_OK;
+  if (!xyz0 || !xyz1 || !K || !out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return proj_nn_f64(xyz0, xyz1, K, B, H, W, patch_size, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -61,4 +61,13 @@ int geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray
                       const float* t0, const float* R1, const float* t1, const float* grad_loss, float* grad_depth0,
                       int accumulate0, float* grad_depth1, int B, int H, int W, float clamp, hipStream_t s);
 
+// nn_ops.hip
+int nn_f32(const float* in0, const float* in1, long n0, long n1, int64_t* out, hipStream_t s);
+int nn_f64(const double* in0, const double* in1, long n0, long n1, int64_t* out, hipStream_t s);
+int crosscheck_i64(const int64_t* in0, const int64_t* in1, long n0, long n1, uint8_t* out, hipStream_t s);
+int proj_nn_f32(const float* xyz0, const float* xyz1, const float* K, long B, long H, long W, int patch_size,
+                int64_t* out, hipStream_t s);
+int proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, long B, long H, long W, int patch_size,
+                int64_t* out, hipStream_t s);
+
 }  // namespace ctd

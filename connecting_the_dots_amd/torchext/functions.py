@@ -56,6 +56,94 @@ def _ptr(t):
 
 
 # --------------------------------------------------------------------------------------
+# Nearest-neighbour consistency ops (reference: NNFunction / CrossCheckFunction / ProjNNFunction,
+# functions.py:5-56; bindings ext_cuda.cpp:17-68)
+# --------------------------------------------------------------------------------------
+class NNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in0, in1):
+        _check(in0, "in0")
+        _check(in1, "in1")
+        dev = _same_device(in0, in1)
+        # shape asserts of the reference binding (ext_cuda.cpp:25-28)
+        if in0.dim() != 2 or in1.dim() != 2:
+            raise RuntimeError("in0 has to be N0 x 3, in1 has to be N1 x 3")
+        if in0.shape[1] != in1.shape[1]:
+            raise RuntimeError("in0 and in1 have to be the same shape")
+        if in0.shape[1] != 3:
+            raise RuntimeError("dim hast to be 3")
+        if in0.dtype != in1.dtype:
+            raise RuntimeError("in0 and in1 must have the same dtype")
+        out = torch.empty((in0.shape[0],), dtype=torch.int64, device=dev)
+        fn = _lib.lib().ctd_nn_f32 if in0.dtype == torch.float32 else _lib.lib().ctd_nn_f64
+        _lib.check(fn(_ptr(in0), _ptr(in1), in0.shape[0], in1.shape[0], _ptr(out), dev.index, _stream(dev)), "nn")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None
+
+
+def nn(in0, in1):
+    """Index of the nearest in1 point [N1,3] for every in0 point [N0,3] (int64 [N0], -1 if none within 1e9)."""
+    return NNFunction.apply(in0, in1)
+
+
+class CrossCheckFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in0, in1):
+        _check(in0, "in0", (torch.int64,))
+        _check(in1, "in1", (torch.int64,))
+        dev = _same_device(in0, in1)
+        if in0.dim() != 1 or in1.dim() != 1:
+            raise RuntimeError("crosscheck expects 1-D index tensors")
+        out = torch.empty((in0.shape[0],), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().ctd_crosscheck(_ptr(in0), _ptr(in1), in0.shape[0], in1.shape[0], _ptr(out), dev.index,
+                                             _stream(dev)), "crosscheck")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None
+
+
+def crosscheck(in0, in1):
+    """uint8 [N0]: 1 where in1[in0[i]] == i (mutual nearest neighbours)."""
+    return CrossCheckFunction.apply(in0, in1)
+
+
+class ProjNNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz0, xyz1, K, patch_size):
+        _check(xyz0, "xyz0")
+        _check(xyz1, "xyz1")
+        _check(K, "K")
+        dev = _same_device(xyz0, xyz1, K)
+        if xyz0.dim() != 4 or xyz1.dim() != 4 or xyz0.shape[3] != 3 or tuple(xyz0.shape) != tuple(xyz1.shape):
+            raise RuntimeError("proj_nn expects xyz0 and xyz1 of the same shape [B,H,W,3]")
+        if K.numel() != 9:
+            raise RuntimeError("K has to be 3 x 3")
+        if not (xyz0.dtype == xyz1.dtype == K.dtype):
+            raise RuntimeError("xyz0, xyz1 and K must have the same dtype")
+        B, H, W, _ = xyz0.shape
+        out = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        fn = _lib.lib().ctd_proj_nn_f32 if xyz0.dtype == torch.float32 else _lib.lib().ctd_proj_nn_f64
+        _lib.check(fn(_ptr(xyz0), _ptr(xyz1), _ptr(K), B, H, W, int(patch_size), _ptr(out), dev.index, _stream(dev)),
+                   "proj_nn")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None, None, None
+
+
+def proj_nn(xyz0, xyz1, K, patch_size):
+    """Flat index (int64 [B,H,W]) of the xyz1 point closest to each xyz0 point inside the patch_size^2 patch
+    around its projection with K; -1 where the patch falls outside the image."""
+    return ProjNNFunction.apply(xyz0, xyz1, K, patch_size)
+
+
+# --------------------------------------------------------------------------------------
 # NCC volume (reference: XCorrVolFunction, functions.py:59-74)
 # --------------------------------------------------------------------------------------
 def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):

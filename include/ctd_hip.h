@@ -195,6 +195,30 @@ int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float*
                           float* grad_depth1, int B, int H, int W, float clamp, int device,
                           void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * Nearest-neighbour consistency ops (integer results, bit-exact).
+ * Replace nn_cuda / crosscheck_cuda / proj_nn_cuda -- torchext/ext/ext_cuda.cpp:17-68,
+ * functors torchext/ext/ext.h:13-117, Python torchext/functions.py:5-56.
+ *   ctd_nn:         in0 [n0][3], in1 [n1][3] -> out int64 [n0] = argmin_j |in0[i] - in1[j]|^2
+ *                   (first index wins ties; -1 if no squared distance is below 1e9)
+ *   ctd_crosscheck: in0 int64 [n0], in1 int64 [n1] -> out uint8 [n0] = 1 where
+ *                   in1[in0[i]] == i (in0[i] truncated to int as in ext.h:61; an index
+ *                   >= n1, which the reference reads out of bounds, gives 0)
+ *   ctd_proj_nn:    xyz0, xyz1 [B][H][W][3], K [3][3] (device) -> out int64 [B][H][W] =
+ *                   flat index of the closest xyz1 point in the patch_size^2 patch around
+ *                   the projection of xyz0 (ext.h:86-114), -1 if the patch is empty
+ * -------------------------------------------------------------------------------------- */
+int ctd_nn_f32(const float* in0, const float* in1, long n0, long n1, int64_t* out, int device,
+               void* stream);
+int ctd_nn_f64(const double* in0, const double* in1, long n0, long n1, int64_t* out, int device,
+               void* stream);
+int ctd_crosscheck(const int64_t* in0, const int64_t* in1, long n0, long n1, uint8_t* out,
+                   int device, void* stream);
+int ctd_proj_nn_f32(const float* xyz0, const float* xyz1, const float* K, int B, int H, int W,
+                    int patch_size, int64_t* out, int device, void* stream);
+int ctd_proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, int B, int H, int W,
+                    int patch_size, int64_t* out, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,21 @@
 #undef SQRT
 #undef FABS
 
+/* ------------------------------------------------------------------------- *
+ * CrossCheckFunctor::operator()   torchext/ext/ext.h:49-66   (host ext_cpu.cpp:39-56)
+ * in0 int64 [n0] (indices into in1), in1 int64 [n1] (indices into in0) -> out u8 [n0]:
+ * 1 where the match is mutual.  `int idx1 = in0[idx0]` truncates to int (ext.h:61).
+ * The reference reads in1[idx1] without an upper bound check (undefined behaviour for
+ * idx1 >= n1); restated as "not mutual".
+ * ------------------------------------------------------------------------- */
+int ctd_oracle_crosscheck(const int64_t* in0, const int64_t* in1, long nelem0, long nelem1, uint8_t* out) {
+  for (long idx0 = 0; idx0 < nelem0; ++idx0) {
+    int idx1 = (int)in0[idx0];
+    out[idx0] = idx1 >= 0 && idx1 < nelem1 && in1[idx1] >= 0 && idx0 == in1[idx1];
+  }
+  return 0;
+}
+
 /* reflect index without repeating the edge (torch.nn.ReflectionPad2d) */
 static inline int reflect_idx(int i, int n) {
   if (i < 0) i = -i;

@@ -218,6 +218,83 @@ int FN(ctd_oracle_photometric_bwd)(const T* es, const T* ta, const T* grad_out,
   return 0;
 }
 
+
+/* ------------------------------------------------------------------------- *
+ * NNFunctor<T,3>::operator()   torchext/ext/ext.h:13-47   (host ext_cpu.cpp:14-36)
+ * in0 [n0,3], in1 [n1,3] -> out int64 [n0]: index of the nearest in1 point
+ * (squared distance accumulated d0,d1,d2 in order; strict <, so the first index
+ * wins ties; -1 when nothing is closer than 1e9).
+ * ------------------------------------------------------------------------- */
+int FN(ctd_oracle_nn)(const T* in0, const T* in1, long nelem0, long nelem1, int64_t* out) {
+  for (long idx0 = 0; idx0 < nelem0; ++idx0) {
+    const T* vec0 = in0 + idx0 * 3;
+    T min_dist = 1e9;                          /* ext.h:29 */
+    long min_arg = -1;
+    for (long idx1 = 0; idx1 < nelem1; ++idx1) {
+      const T* vec1 = in1 + idx1 * 3;
+      T dist = 0;
+      for (long didx = 0; didx < 3; ++didx) {
+        T diff = vec0[didx] - vec1[didx];
+        dist += diff * diff;                   /* ext.h:36 */
+      }
+      if (dist < min_dist) {                   /* ext.h:39 */
+        min_dist = dist;
+        min_arg = idx1;
+      }
+    }
+    out[idx0] = min_arg;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * ProjNNFunctor<T,3>::operator()   torchext/ext/ext.h:68-117   (host ext_cpu.cpp:59-86)
+ * xyz0, xyz1 [B,H,W,3] (both in the coordinate system of view 1), K [3,3] ->
+ * out int64 [B,H,W]: flat index (b*H + v)*W + u of the closest xyz1 point inside
+ * the patch_size^2 patch around the projection of xyz0; -1 if the patch is empty.
+ * `int u0 = u + 0.5` promotes to double and truncates toward zero (ext.h:94-95).
+ * Projections that do not fit an int are undefined behaviour in the reference
+ * (x86: INT_MIN, patch out of the image); restated as "no candidate".
+ * ------------------------------------------------------------------------- */
+int FN(ctd_oracle_proj_nn)(const T* xyz0, const T* xyz1, const T* K, long batch_size, long height,
+                           long width, long patch_size, int64_t* out) {
+  const long N = batch_size * height * width;
+  for (long idx0 = 0; idx0 < N; ++idx0) {
+    const long bs = idx0 / (height * width);
+    const T x = xyz0[idx0 * 3 + 0];
+    const T y = xyz0[idx0 * 3 + 1];
+    const T z = xyz0[idx0 * 3 + 2];
+    const T d = K[6] * x + K[7] * y + K[8] * z;
+    const T u = (K[0] * x + K[1] * y + K[2] * z) / d;
+    const T v = (K[3] * x + K[4] * y + K[5] * z) / d;
+    const double ud = u + 0.5, vd = v + 0.5;
+    long min_idx1 = -1;
+    if (ud > -2147483649.0 && ud < 2147483648.0 && vd > -2147483649.0 && vd < 2147483648.0) {
+      int u0 = (int)ud;
+      int v0 = (int)vd;
+      T min_dist = 1e9;
+      for (int pidx = 0; pidx < patch_size * patch_size; ++pidx) {
+        int pu = pidx % patch_size;
+        int pv = pidx / patch_size;
+        long u1 = (long)u0 + pu - patch_size / 2;
+        long v1 = (long)v0 + pv - patch_size / 2;
+        if (u1 >= 0 && v1 >= 0 && u1 < width && v1 < height) {
+          const long idx1 = (bs * height + v1) * width + u1;
+          const T* xyz1n = xyz1 + idx1 * 3;
+          const T dd = (x - xyz1n[0]) * (x - xyz1n[0]) + (y - xyz1n[1]) * (y - xyz1n[1]) +
+                       (z - xyz1n[2]) * (z - xyz1n[2]);          /* ext.h:108 */
+          if (dd < min_dist) {
+            min_dist = dd;
+            min_idx1 = idx1;
+          }
+        }
+      }
+    }
+    out[idx0] = min_idx1;
+  }
+  return 0;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -141,3 +141,35 @@ def disp_to_depth(disp, bf):
     fn.argtypes = [_vp, _vp, _c_long, _c_float]
     assert fn(_p(disp), _p(out), disp.size, bf) == 0
     return out
+
+
+def nn(in0, in1):
+    """[n0,3] x [n1,3] -> int64 [n0]   (ext.h:13-47)"""
+    in0, in1 = _c(in0), _c(in1, in0.dtype)
+    out = np.empty((in0.shape[0],), np.int64)
+    fn = getattr(lib(), "ctd_oracle_nn_" + _sfx(in0))
+    fn.argtypes = [_vp, _vp, _c_long, _c_long, _vp]
+    assert fn(_p(in0), _p(in1), in0.shape[0], in1.shape[0], _p(out)) == 0
+    return out
+
+
+def crosscheck(in0, in1):
+    """int64 [n0] x int64 [n1] -> uint8 [n0]   (ext.h:49-66)"""
+    in0, in1 = _c(in0, np.int64), _c(in1, np.int64)
+    out = np.empty((in0.shape[0],), np.uint8)
+    fn = lib().ctd_oracle_crosscheck
+    fn.argtypes = [_vp, _vp, _c_long, _c_long, _vp]
+    assert fn(_p(in0), _p(in1), in0.shape[0], in1.shape[0], _p(out)) == 0
+    return out
+
+
+def proj_nn(xyz0, xyz1, K, patch_size):
+    """[B,H,W,3] x2, K [3,3] -> int64 [B,H,W]   (ext.h:68-117)"""
+    xyz0 = _c(xyz0)
+    xyz1, K = _c(xyz1, xyz0.dtype), _c(K, xyz0.dtype)
+    B, H, W, _ = xyz0.shape
+    out = np.empty((B, H, W), np.int64)
+    fn = getattr(lib(), "ctd_oracle_proj_nn_" + _sfx(xyz0))
+    fn.argtypes = [_vp, _vp, _vp, _c_long, _c_long, _c_long, _c_long, _vp]
+    assert fn(_p(xyz0), _p(xyz1), _p(K), B, H, W, patch_size, _p(out)) == 0
+    return out

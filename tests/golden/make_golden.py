@@ -29,6 +29,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 import torch  # noqa: E402
 
 from oracle import build_ref, ref_python  # noqa: E402
+from tests import workloads  # noqa: E402
 
 warnings.filterwarnings("ignore")
 torch.set_num_threads(4)
@@ -302,10 +303,25 @@ def gen_pattern_loss(nets):
     save("pattern_loss", **out)
 
 
+def gen_nn_ops(ext):
+    """nn_cpu / crosscheck_cpu / proj_nn_cpu of the compiled reference (ext_cpu.cpp:14-86)"""
+    out = {}
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        a, b = workloads.nn_case(3, dt)
+        i01 = ext.nn_cpu(t(a), t(b)).numpy()
+        i10 = ext.nn_cpu(t(b), t(a)).numpy()
+        out["nn01_" + tag], out["nn10_" + tag] = i01, i10
+        out["cc_" + tag] = ext.crosscheck_cpu(t(i01), t(i10)).numpy()
+        xyz0, xyz1, K = workloads.proj_case(4, dt)
+        for ps in (1, 3, 4, 5):
+            out["proj%d_%s" % (ps, tag)] = ext.proj_nn_cpu(t(xyz0), t(xyz1), t(K), ps).numpy()
+    save("nn_ops", **out)
+
+
 def main():
     ext = build_ref.load()
     te, nets = ref_python.load()
-    which = sys.argv[1:] or ["xcorr", "photo", "costvol", "lcn", "lcncy", "losses", "patloss", "cfg1"]
+    which = sys.argv[1:] or ["xcorr", "photo", "costvol", "lcn", "lcncy", "losses", "patloss", "nnops", "cfg1"]
     if "xcorr" in which:
         gen_xcorrvol(ext)
     if "photo" in which:
@@ -320,6 +336,8 @@ def main():
         gen_losses(nets)
     if "patloss" in which:
         gen_pattern_loss(nets)
+    if "nnops" in which:
+        gen_nn_ops(ext)
     if "cfg1" in which:
         gen_cfg1(ext)
 

@@ -52,8 +52,9 @@ def test_workspace_query_and_validation_need_no_gpu():
 
 def test_python_surface_mirrors_reference_names():
     from connecting_the_dots_amd import torchext as te
-    for name in ("xcorrvol", "XCorrVolFunction", "photometric_loss", "PhotometricLossFunction",
-                 "photometric_loss_pytorch", "CoordConv2d"):
+    for name in ("nn", "NNFunction", "crosscheck", "CrossCheckFunction", "proj_nn", "ProjNNFunction", "xcorrvol",
+                 "XCorrVolFunction", "photometric_loss", "PhotometricLossFunction", "photometric_loss_pytorch",
+                 "CoordConv2d"):
         assert hasattr(te, name), name
     for name in ("xcorrvol_batch", "xcorrvol_argmax", "argmax_disp", "lcn", "LCN", "costvol", "disp_to_depth",
                  "disparity_loss", "geometric_loss", "DispToDepth", "DisparityLoss", "ProjectionDepthSimilarityLoss",

@@ -122,3 +122,18 @@ def test_disp_to_depth(oracle):
     g = golden("losses")
     d = oracle.disp_to_depth(g["d2d_disp"], float(g["d2d_bf"]))
     assert_close(d, g["d2d_depth"], rtol=1e-6, atol=0, what="depth")
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+def test_nn_crosscheck_proj_nn_bit_exact(oracle, tag, dt):
+    """ext.h:13-117 restated; goldens from the compiled reference's nn_cpu / crosscheck_cpu / proj_nn_cpu."""
+    from tests import workloads
+    g = golden("nn_ops")
+    a, b = workloads.nn_case(3, dt)
+    i01, i10 = oracle.nn(a, b), oracle.nn(b, a)
+    assert np.array_equal(i01, g["nn01_" + tag]) and np.array_equal(i10, g["nn10_" + tag])
+    assert i01[5] == 10 and i01[7] == -1                    # first index wins the tie; nothing within 1e9 -> -1
+    assert np.array_equal(oracle.crosscheck(i01, i10), g["cc_" + tag])
+    xyz0, xyz1, K = workloads.proj_case(4, dt)
+    for ps in (1, 3, 4, 5):
+        assert np.array_equal(oracle.proj_nn(xyz0, xyz1, K, ps), g["proj%d_%s" % (ps, tag)]), ps

@@ -32,3 +32,27 @@ def synth_ir(pattern01, rs, D=128, block=(48, 64)):
     ambient = rs.uniform(0, 1, size=(H, W))
     ir = 0.6 * shifted + 0.4 * ambient + rs.normal(0, 3.0 / 255, size=(H, W))
     return np.clip(ir, 0, 1).astype(np.float32), disp
+
+
+def nn_case(seed, dt, n0=300, n1=257):
+    """seeded point clouds with exact duplicates (ties) for nn / crosscheck; shared with the tests"""
+    rs = np.random.RandomState(seed)
+    a = rs.normal(size=(n0, 3)).astype(dt)
+    b = rs.normal(size=(n1, 3)).astype(dt)
+    b[10] = b[200]
+    a[5] = b[200]
+    a[7] = 1e6            # farther than sqrt(1e9) from everything: no match, -1
+    return a, b
+
+
+def proj_case(seed, dt, B=2, H=24, W=32):
+    rs = np.random.RandomState(seed)
+    K = np.array([[30., 0, 16], [0, 30, 12], [0, 0, 1]], dt)
+    z = rs.uniform(1, 3, size=(B, H, W)).astype(dt)
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    xyz1 = np.stack([(u - 16) / 30 * z, (v - 12) / 30 * z, z], -1).astype(dt)
+    xyz0 = (xyz1 + rs.normal(scale=0.05, size=xyz1.shape)).astype(dt)
+    xyz0[0, 0, 0] = [0, 0, 0]      # d = 0: NaN projection
+    xyz0[0, 0, 1] = [1, 1, 0]      # infinite projection
+    xyz0[1, 3, 4] = [-50, 0, 1]    # projects far left of the image
+    return xyz0, xyz1, K
