@@ -1,0 +1,122 @@
+// ctd_ncc_point.h -- one NCC output in the reference's operation order, straight from global memory.
+// XCorrVolFunctor<T>::operator()  /root/reference/torchext/ext/ext.h:120-191 (two passes over the window,
+// means first, channels accumulated in order).  Used by the generic fallback kernel and by the fix-up pass
+// of the fast path; bit-identical to the reference's FMA-free CPU build.
+#ifndef CTD_NCC_POINT_H
+#define CTD_NCC_POINT_H
+#include "ctd_common.h"
+
+namespace ctd {
+
+__device__ inline float ncc_norm(float s0, float s1) {
+  // T norm = sqrt(sigma0 * sigma1) + 1e-8;  sqrt in float, the add in double (ext.h:185)
+  return (float)((double)sqrtf(s0 * s1) + 1e-8);
+}
+__device__ inline double ncc_norm(double s0, double s1) { return sqrt(s0 * s1) + 1e-8; }
+
+// a, b: [C][H][W] planes of one frame / its pattern
+template <typename T>
+__device__ inline T ncc_reference_point(const T* __restrict__ a, const T* __restrict__ b, int C, int H, int W, int h,
+                                        int w, int d, int bs) {
+  const long HW = (long)H * W;
+  const int half = bs / 2;
+  const T bs2 = (T)(bs * bs);
+  T val = 0;
+  for (int c = 0; c < C; ++c) {
+    T mu0 = 0, mu1 = 0;
+    for (int bh = 0; bh < bs; ++bh) {
+      int hh = clampi(h + bh - half, 0, H - 1);
+      for (int bw = 0; bw < bs; ++bw) {
+        int w0 = w + bw - half;
+        int w1 = clampi(w0 - d, 0, W - 1);
+        w0 = clampi(w0, 0, W - 1);
+        mu0 += a[(long)c * HW + (long)hh * W + w0] / bs2;
+        mu1 += b[(long)c * HW + (long)hh * W + w1] / bs2;
+      }
+    }
+    T s0 = 0, s1 = 0, dot = 0;
+    for (int bh = 0; bh < bs; ++bh) {
+      int hh = clampi(h + bh - half, 0, H - 1);
+      for (int bw = 0; bw < bs; ++bw) {
+        int w0 = w + bw - half;
+        int w1 = clampi(w0 - d, 0, W - 1);
+        w0 = clampi(w0, 0, W - 1);
+        T v0 = a[(long)c * HW + (long)hh * W + w0] - mu0;
+        T v1 = b[(long)c * HW + (long)hh * W + w1] - mu1;
+        dot += v0 * v1;
+        s0 += v0 * v0;
+        s1 += v1 * v1;
+      }
+    }
+    val += dot / ncc_norm(s0, s1);
+  }
+  return val;
+}
+
+// reference-order NCC of one disparity from windows staged in LDS: sA[bs][bs] is the frame window,
+// sB[bs][bs + D - 1] the pattern rows from column w - half - (D-1) on (replicate border baked in), so tap
+// (bh, bw) of disparity d sits at sB[bh][bw + (D-1) - d].  Same operation order as ncc_exact_point.
+// `dot / norm` of one channel (ext.h:186 adds it to the running `val`)
+__device__ inline float ncc_exact_term_lds(const float* sA, const float* sB, int bs, int span, int off) {
+  const float bs2 = (float)(bs * bs);
+  float mu0 = 0.f, mu1 = 0.f;
+  for (int bh = 0; bh < bs; ++bh)
+    for (int bw = 0; bw < bs; ++bw) {
+      mu0 += sA[bh * bs + bw] / bs2;
+      mu1 += sB[bh * span + bw + off] / bs2;
+    }
+  float s0 = 0.f, s1 = 0.f, dot = 0.f;
+  for (int bh = 0; bh < bs; ++bh)
+    for (int bw = 0; bw < bs; ++bw) {
+      const float v0 = sA[bh * bs + bw] - mu0;
+      const float v1 = sB[bh * span + bw + off] - mu1;
+      dot += v0 * v1;
+      s0 += v0 * v0;
+      s1 += v1 * v1;
+    }
+  return dot / ncc_norm(s0, s1);
+}
+__device__ inline float ncc_exact_point_lds(const float* sA, const float* sB, int bs, int span, int off) {
+  float val = 0.f;
+  val += ncc_exact_term_lds(sA, sB, bs, span, off);
+  return val;
+}
+
+// Same value, computed by a whole wavefront: lane t (and t + 64) owns tap t of the window, the per-tap terms
+// are formed in parallel and only the reference's tap-order accumulations run serially, fed by v_readlane.
+// Bit-identical to ncc_exact_point_lds (same operations on the same operands in the same order), but a
+// few hundred register-only instructions instead of a latency chain of ~650 dependent LDS reads.
+__device__ inline float ncc_exact_point_wave(const float* sA, const float* sB, int bs, int span, int off, int lane) {
+  const int n = bs * bs;                                  // <= 128 taps (bs <= 11)
+  const float bs2 = (float)n;
+  const int t0 = lane, t1 = lane + 64;
+  const bool h0 = t0 < n, h1 = t1 < n;
+  const float a0 = h0 ? sA[t0] : 0.f, a1 = h1 ? sA[t1] : 0.f;
+  const float b0 = h0 ? sB[(t0 / bs) * span + (t0 % bs) + off] : 0.f;
+  const float b1 = h1 ? sB[(t1 / bs) * span + (t1 % bs) + off] : 0.f;
+  const float qa0 = a0 / bs2, qa1 = a1 / bs2, qb0 = b0 / bs2, qb1 = b1 / bs2;
+  float mu0 = 0.f, mu1 = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int l = t & 63;
+    const float xa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qa0 : qa1), l));
+    const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qb0 : qb1), l));
+    mu0 += xa;
+    mu1 += xb;
+  }
+  const float va0 = a0 - mu0, va1 = a1 - mu0, vb0 = b0 - mu1, vb1 = b1 - mu1;
+  const float pd0 = va0 * vb0, pd1 = va1 * vb1, pa0 = va0 * va0, pa1 = va1 * va1, pb0 = vb0 * vb0, pb1 = vb1 * vb1;
+  float dot = 0.f, s0 = 0.f, s1 = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int l = t & 63;
+    dot += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pd0 : pd1), l));
+    s0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pa0 : pa1), l));
+    s1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pb0 : pb1), l));
+  }
+  const float norm = (float)((double)sqrtf(s0 * s1) + 1e-8);
+  float val = 0.f;
+  val += dot / norm;
+  return val;
+}
+
+}  // namespace ctd
+#endif

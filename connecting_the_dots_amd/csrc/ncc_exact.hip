@@ -17,6 +17,7 @@
 // This kernel is VALU-bound by construction (3 non-fusable f32 ops per tap per output,
 // >= 243 ops per output for bs = 9); the HBM-roofline kernel is ncc_fast.hip.
 #include "ctd_internal.h"
+#include "ctd_ncc_point.h"
 
 namespace ctd {
 
@@ -64,12 +65,6 @@ __global__ void window_stats_kernel(const T* __restrict__ in, long frame_stride,
   stats[2 * i] = mu;
   stats[2 * i + 1] = sigma;
 }
-
-__device__ inline float ncc_norm(float s0, float s1) {
-  // T norm = sqrt(sigma0 * sigma1) + 1e-8;  sqrt in float, the add in double (ext.h:185)
-  return (float)((double)sqrtf(s0 * s1) + 1e-8);
-}
-__device__ inline double ncc_norm(double s0, double s1) { return sqrt(s0 * s1) + 1e-8; }
 
 // ---------------------------------------------------------------------------------
 // main kernel, f32, compile-time block size.
@@ -208,40 +203,7 @@ __global__ void ncc_direct_kernel(const T* __restrict__ in0, const T* __restrict
   int h = (int)((i / W) % H);
   int d = (int)((i / HW) % D);
   int f = (int)(i / (HW * D));
-  const T* a = in0 + (long)f * C * HW;
-  const T* b = in1 + (long)f * in1_frame_stride;
-  const int half = bs / 2;
-  const T bs2 = (T)(bs * bs);
-  T val = 0;
-  for (int c = 0; c < C; ++c) {
-    T mu0 = 0, mu1 = 0;
-    for (int bh = 0; bh < bs; ++bh) {
-      int hh = clampi(h + bh - half, 0, H - 1);
-      for (int bw = 0; bw < bs; ++bw) {
-        int w0 = w + bw - half;
-        int w1 = clampi(w0 - d, 0, W - 1);
-        w0 = clampi(w0, 0, W - 1);
-        mu0 += a[(long)c * HW + (long)hh * W + w0] / bs2;
-        mu1 += b[(long)c * HW + (long)hh * W + w1] / bs2;
-      }
-    }
-    T s0 = 0, s1 = 0, dot = 0;
-    for (int bh = 0; bh < bs; ++bh) {
-      int hh = clampi(h + bh - half, 0, H - 1);
-      for (int bw = 0; bw < bs; ++bw) {
-        int w0 = w + bw - half;
-        int w1 = clampi(w0 - d, 0, W - 1);
-        w0 = clampi(w0, 0, W - 1);
-        T v0 = a[(long)c * HW + (long)hh * W + w0] - mu0;
-        T v1 = b[(long)c * HW + (long)hh * W + w1] - mu1;
-        dot += v0 * v1;
-        s0 += v0 * v0;
-        s1 += v1 * v1;
-      }
-    }
-    val += dot / ncc_norm(s0, s1);
-  }
-  out[i] = val;
+  out[i] = ncc_reference_point(in0 + (long)f * C * HW, in1 + (long)f * in1_frame_stride, C, H, W, h, w, d, bs);
 }
 
 // argmax over d of a materialised volume; first index wins (strict >), one thread per pixel.

@@ -30,7 +30,11 @@
 #include <type_traits>
 
 #include "ctd_internal.h"
+#include "ctd_ncc_point.h"
 
+#ifndef CTD_FIX_ABLATE
+#define CTD_FIX_ABLATE 0   // timing experiments only
+#endif
 #ifndef CTD_ABLATE2
 #define CTD_ABLATE2 0   // bit 0: no DPP combine, bit 1: no finalize, bit 2: no pattern-side LDS reads, bit 3: no vertical tree
 #endif
@@ -55,6 +59,7 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
 constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
+constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(kPairLimit) - 1
 
 // out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
@@ -63,7 +68,12 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
                                                                   float* __restrict__ out_img,
                                                                   float* __restrict__ out_mean,
                                                                   float* __restrict__ out_dev, int H, int W,
-                                                                  int x_start, int W_out, int bs) {
+                                                                  int x_start, int W_out, int bs,
+                                                                  unsigned* __restrict__ n_flag,
+                                                                  unsigned long long* __restrict__ flag_list,
+                                                                  int col_lo, int col_hi,
+                                                                  unsigned* __restrict__ n_runs,
+                                                                  unsigned long long* __restrict__ run_rows) {
   extern __shared__ double lds_d[];
   __shared__ double cred[kSTW * kSRows];
   const int half = bs / 2;
@@ -122,6 +132,239 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
     out_mean[o] = (float)(mean - (double)cval);
     out_dev[o] = (float)sqrt(var > 0 ? var : 0.0);
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
+    // Window whose deviation is small against its offset from the centring constant: cov = S_ab - n*ma*mb
+    // loses accuracy to cancellation in f32.  Listed for ncc_fixup_kernel (see there).
+    const double mc = mean - (double)cval;
+    const int col = xi + x_start;
+    if (n * mc * mc > kFlagRatio * var && col >= col_lo && col < col_hi)
+    {
+      flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)blockIdx.z << 40) | ((unsigned long long)h << 20) |
+                                         (unsigned long long)(col + 0x80000);
+      if (run_rows && col == col_lo) run_rows[atomicAdd(n_runs, 1u)] = ((unsigned long long)blockIdx.z << 20) | (unsigned long long)h;
+    }
+  }
+}
+
+// Fix-up pass of the fast path.
+//
+// Error model of the fast kernel (tools/err_vs_factor.py): cov = S_ab - n*ma*mb is formed from values
+// centred by one constant per image, so |fast - exact| <~ c * 2^-24 * sqrt(Fa * Fb) with
+// F = 1 + n*(window mean - centring)^2 / (sum of squared deviations) per window and c <= ~6 (ten f32
+// roundings along the longest summation path).  The contract |a-b| <= 1e-5|b| + 1e-6 therefore holds
+// whenever Fa * Fb <= kPairLimit; LCN'd input has F ~ 1 except in flat regions and in the low-variance
+// windows clamped to column 0.  The pre-pass lists every window with F > sqrt(kPairLimit); this kernel
+// visits the listed windows, checks each (frame window, pattern window) pair they take part in and
+// recomputes the offending outputs in the reference's operation order (bit-identical to CTD_NCC_EXACT).
+// One wavefront per listed window, lane <-> disparity; the window itself (FIX, bs x bs) and the rows of
+// the other image it meets over all disparities (SPAN, bs x (bs + D - 1)) are staged in LDS per channel.
+//   frame window  (f, h, w): outputs (f, d, h, w);        SPAN = pattern columns w-half-(D-1) .. w+half
+//   pattern window (p, h, x): outputs (f, d, h, x + d), 0 <= x + d < W, every frame f that uses p;
+//                             SPAN = frame columns x-half .. x+(D-1)+half.  x = -(bs-1-half) stands for all
+//                             fully clamped windows x <= -(bs-1-half): lane d's value is written to the
+//                             whole run d' >= d of pixel w = x + d (ext.h:152-154 makes the run constant).
+// The NCC is symmetric in the two windows (dot and sigma0*sigma1 commute exactly), so one staging layout
+// serves both cases.
+constexpr float kPairLimit = 8.f;
+
+__device__ inline float cond_factor(float mean_c, float dev, float n) {
+  const float num = n * mean_c * mean_c, var = dev * dev;
+  return num > 0.f ? 1.f + num / var : 1.f;              // var == 0 with an offset: +inf
+}
+
+// Loops over the window rows stay rolled (a fully unrolled body is ~40 KB of straight-line code that every
+// wavefront executes once -- instruction-fetch bound); BS > 0 unrolls the inner tap loop only.
+// Outputs of the fully clamped run are not written here (one store per disparity plane and lane thrashes
+// the TLB): the run's value goes to `run_vals[f][h][d_first]` (NaN = keep the fast value) and
+// ncc_fixup_runs_kernel spreads it plane by plane.
+template <int BS>
+__global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                        long in1_frame_stride, float* __restrict__ out,
+                                                        const float* __restrict__ m0, const float* __restrict__ v0,
+                                                        const float* __restrict__ m1, const float* __restrict__ v1,
+                                                        long st1_frame_stride, int Wp, int W1, int xoff,
+                                                        const unsigned* __restrict__ counters,
+                                                        const unsigned long long* __restrict__ list_a,
+                                                        const unsigned long long* __restrict__ list_b,
+                                                        float* __restrict__ run_vals, int frames, int C, int H, int W,
+                                                        int D, int bs_rt) {
+  extern __shared__ float lds_fix[];
+  const int bs = BS > 0 ? BS : bs_rt;
+  const int lane = threadIdx.x & 63;
+  const int half = bs / 2, span = bs + D - 1, taps = bs * bs;
+  const float n = (float)taps;
+  // per-wave staging: FIX window raw / divided by n / minus its mean, SPAN rows raw / divided by n
+  float* sF = lds_fix + (threadIdx.x >> 6) * (3 * taps + 2 * bs * span);
+  float* sFq = sF + taps;
+  float* sFv = sFq + taps;
+  float* sS = sFv + taps;
+  float* sSq = sS + bs * span;
+  const long HW = (long)H * W;
+  const unsigned n_a = counters[0], n_b = counters[1];
+  const unsigned per_b = in1_frame_stride == 0 ? (unsigned)frames : 1u;   // a shared pattern window meets every frame
+  const unsigned n_items = n_a + n_b * per_b;
+  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+  const int rounds = (D + 63) / 64;
+  for (unsigned item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
+    const bool is_a = item < n_a;
+    const unsigned jb = is_a ? 0u : (item - n_a) / per_b;
+    const unsigned long long e = is_a ? list_a[item] : list_b[jb];
+    const int z = (int)(e >> 40), h = (int)((e >> 20) & 0xFFFFF), col = (int)(e & 0xFFFFF) - 0x80000;
+    const int f = (is_a || per_b == 1u) ? z / C : (int)((item - n_a) - jb * per_b);
+    const bool run_item = !is_a && col == -(bs - 1 - half);
+    const float* fix_img = is_a ? in0 + (long)f * C * HW : in1 + (long)f * in1_frame_stride;
+    const float* span_img = is_a ? in1 + (long)f * in1_frame_stride : in0 + (long)f * C * HW;
+    const int span_col0 = is_a ? col - half - (D - 1) : col - half;
+    int staged_c = -1;
+    float mu_f = 0.f, s_f = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+      const int d = r * 64 + lane;
+      const int w = is_a ? col : col + d;
+      // is this output out of the fast kernel's accuracy range? (any channel)
+      bool bad = false;
+      if (d < D && w >= 0 && w < W) {
+        for (int c = 0; c < C; ++c) {
+          const long oa = (((long)f * C + c) * H + h) * Wp + w + 4;
+          const long ob = (long)f * st1_frame_stride + ((long)c * H + h) * W1 + (w - d) + xoff;
+          bad = bad | (cond_factor(m0[oa], v0[oa], n) * cond_factor(m1[ob], v1[ob], n) > kPairLimit);
+        }
+      }
+#if CTD_FIX_ABLATE == 3
+      bad = false;
+#endif
+      float val = 0.f;
+      if (__any(bad)) {
+        for (int c = 0; c < C; ++c) {
+          if (staged_c != c) {
+            staged_c = c;
+            // batches of independent loads: a lone wavefront must not pay one memory round trip per element
+            for (int i0 = lane; i0 < taps; i0 += 64 * 2) {
+              float t[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int i = min(i0 + 64 * u, taps - 1);
+                const int bh = i / bs, bw = i - bh * bs;
+                t[u] = fix_img[(long)c * HW + (long)clampi(h + bh - half, 0, H - 1) * W + clampi(col + bw - half, 0, W - 1)];
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (i0 + 64 * u < taps) {
+                  sF[i0 + 64 * u] = t[u];
+                  sFq[i0 + 64 * u] = t[u] / n;            // the reference divides every tap before summing
+                }
+            }
+            for (int i0 = lane; i0 < bs * span; i0 += 64 * 8) {
+              float t[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + 64 * u, bs * span - 1);
+                const int bh = i / span, cc = i - bh * span;
+                t[u] = span_img[(long)c * HW + (long)clampi(h + bh - half, 0, H - 1) * W + clampi(span_col0 + cc, 0, W - 1)];
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (i0 + 64 * u < bs * span) {
+                  sS[i0 + 64 * u] = t[u];
+                  sSq[i0 + 64 * u] = t[u] / n;
+                }
+            }
+            // the FIX side (mean, deviations, sigma) is the same for every disparity: once per staging
+            mu_f = 0.f;
+            for (int bh = 0; bh < bs; ++bh) {
+#pragma unroll
+              for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) mu_f += sFq[bh * BS + bw];
+              if (BS == 0)
+                for (int bw = 0; bw < bs; ++bw) mu_f += sFq[bh * bs + bw];
+            }
+            for (int i = lane; i < taps; i += 64) sFv[i] = sF[i] - mu_f;
+            s_f = 0.f;
+            for (int bh = 0; bh < bs; ++bh) {
+#pragma unroll
+              for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) s_f += sFv[bh * BS + bw] * sFv[bh * BS + bw];
+              if (BS == 0)
+                for (int bw = 0; bw < bs; ++bw) s_f += sFv[bh * bs + bw] * sFv[bh * bs + bw];
+            }
+          }
+          if (bad && CTD_FIX_ABLATE != 2) {
+            const int off = is_a ? (D - 1) - d : d;
+            float mu_s = 0.f, s_s = 0.f, dot = 0.f;
+            for (int bh = 0; bh < bs; ++bh) {
+              const float* q = sSq + bh * span + off;
+#pragma unroll
+              for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) mu_s += q[bw];
+              if (BS == 0)
+                for (int bw = 0; bw < bs; ++bw) mu_s += q[bw];
+            }
+            for (int bh = 0; bh < bs; ++bh) {
+              const float* x = sS + bh * span + off;
+              const float* vf = sFv + bh * bs;
+#pragma unroll
+              for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) {
+                const float vs = x[bw] - mu_s;
+                dot += vf[bw] * vs;
+                s_s += vs * vs;
+              }
+              if (BS == 0)
+                for (int bw = 0; bw < bs; ++bw) {
+                  const float vs = x[bw] - mu_s;
+                  dot += vf[bw] * vs;
+                  s_s += vs * vs;
+                }
+            }
+            val += dot / ncc_norm(s_f, s_s);              // ext.h:185-186 (sigma0 * sigma1 commutes)
+          }
+        }
+      }
+      if (run_item) {
+        if (d < D) run_vals[((long)f * H + h) * D + d] = bad ? val : __int_as_float(0x7fc00000);
+      } else if (bad) {
+        out[((long)f * D + d) * HW + (long)h * W + w] = val;
+      }
+    }
+  }
+}
+
+// Second half of the run items: one workgroup per (frame, disparity plane) copies, for every listed fully
+// clamped pattern window (row h, from `run_rows`), the run values of the pixels w <= d - tail whose run has
+// started (first disparity w + tail <= d) into its plane -- all stores of a workgroup land in one plane,
+// (row, w) pairs are flattened over the threads so that every thread has independent loads in flight.
+__global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__ out, const float* __restrict__ run_vals,
+                                                             const unsigned* __restrict__ counters,
+                                                             const unsigned long long* __restrict__ run_rows, int per_frame,
+                                                             int frames, int C, int H, int W, int D, int bs) {
+  extern __shared__ int s_rows[];                          // up to C * H rows of this frame's pattern
+  __shared__ int s_n;
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x / D, d = blockIdx.x - f * D;
+  const int tail = bs - 1 - bs / 2;
+  const int seg = min(d - tail + 1, W);                    // pixels w in [0, d - tail]
+  const unsigned n_r = counters[2];
+  if (seg <= 0 || n_r == 0) return;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (unsigned j = tid; j < n_r; j += blockDim.x) {
+    const unsigned long long e = run_rows[j];
+    const int z = (int)(e >> 20), h = (int)(e & 0xFFFFF);
+    // rows are dealt to the gridDim.y workgroups of a plane by h (late planes carry ~D pixels per row)
+    if ((!per_frame || z / C == f) && h % (int)gridDim.y == (int)blockIdx.y) s_rows[atomicAdd(&s_n, 1)] = h;
+  }
+  __syncthreads();
+  const long HW = (long)H * W;
+  const long total = (long)s_n * seg;
+  constexpr int kU = 8;
+  for (long e0 = tid; e0 < total; e0 += 256 * kU) {
+    float v[kU];
+    long o[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long e = min(e0 + 256 * u, total - 1);
+      const int j = (int)(e / seg), w = (int)(e - (long)j * seg);
+      const int h = s_rows[j];
+      v[u] = run_vals[((long)f * H + h) * D + w + tail];
+      o[u] = ((long)f * D + d) * HW + (long)h * W + w;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (e0 + 256 * u < total && v[u] == v[u]) out[o[u]] = v[u];
   }
 }
 
@@ -1023,6 +1266,10 @@ struct FastWorkspace {
   float *bc, *m1, *v1;        // same for the pattern, per UNCLAMPED window-centre column          [..][H][W1]
   int Wp;                     // frame plane row pitch: W + 8, column c lives at c + 4 (replicate border baked in)
   int W1, xoff;               // pattern plane row pitch and origin: column x lives at x + xoff
+  unsigned* counters;         // [0] flagged frame windows, [1] flagged pattern windows (see ncc_fixup_kernel)
+  unsigned long long *flag_a, *flag_b;
+  unsigned long long* run_rows;   // (pattern image << 20 | h) of the listed fully clamped pattern windows
+  float* run_vals;            // [frames][H][D] exact values of the fully clamped runs (ncc_fixup_runs_kernel)
   size_t bytes;
 };
 
@@ -1044,7 +1291,16 @@ static FastWorkspace fast_workspace(void* base, int frames, int C, int H, int W,
   ws.bc = (float*)(p + 3 * n0);
   ws.m1 = (float*)(p + 3 * n0 + n1);
   ws.v1 = (float*)(p + 3 * n0 + 2 * n1);
-  ws.bytes = 3 * n0 + 3 * n1;
+  // flag lists: room for every frame window and every pattern window the outputs can touch
+  size_t nfa = align_up((size_t)frames * C * H * W * sizeof(unsigned long long), 256);
+  size_t nfb = align_up((size_t)(per_frame_pattern ? frames : 1) * C * H * ws.W1 * sizeof(unsigned long long), 256);
+  ws.counters = (unsigned*)(p + 3 * n0 + 3 * n1);
+  ws.flag_a = (unsigned long long*)(p + 3 * n0 + 3 * n1 + 256);
+  ws.flag_b = (unsigned long long*)(p + 3 * n0 + 3 * n1 + 256 + nfa);
+  size_t nrr = align_up((size_t)(per_frame_pattern ? frames : 1) * C * H * sizeof(unsigned long long), 256);
+  ws.run_rows = (unsigned long long*)(p + 3 * n0 + 3 * n1 + 256 + nfa + nfb);
+  ws.run_vals = (float*)(p + 3 * n0 + 3 * n1 + 256 + nfa + nfb + nrr);
+  ws.bytes = 3 * n0 + 3 * n1 + 256 + nfa + nfb + nrr + align_up((size_t)frames * H * D * sizeof(float), 256);
   return ws;
 }
 
@@ -1054,14 +1310,14 @@ size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, 
 }
 
 static int launch_prepass(const float* in, long frame_stride, int nimg, float* cimg, float* mean, float* dev, int H,
-                          int W, int x_start,
-                        int W_out, int bs, hipStream_t stream) {
+                          int W, int x_start, int W_out, int bs, unsigned* n_flag, unsigned long long* flag_list,
+                          int col_lo, int col_hi, unsigned* n_runs, unsigned long long* run_rows, hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
   dim3 grid(ceil_div(W_out, kSTW), ceil_div(H, kSTH), nimg), block(kSTW, kSRows);
   hipLaunchKernelGGL(ncc_prepass_kernel, grid, block, lds, stream, in, frame_stride, cimg, mean, dev, H, W, x_start, W_out,
-                     bs);
+                     bs, n_flag, flag_list, col_lo, col_hi, n_runs, run_rows);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -1144,26 +1400,50 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
+  if (H >= (1 << 20) || W + D >= (1 << 19) || D > 512 || (long)frames * C >= (1 << 24)) return CTD_ERR_UNSUPPORTED;
   const bool per_frame = in1_frame_stride != 0;
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
-  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, -4, ws.Wp, bs, stream);
+  CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
+  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, -4, ws.Wp, bs, ws.counters,
+                          ws.flag_a, 0, W, nullptr, nullptr, stream);
   if (st) return st;
-  // pattern statistics per unclamped centre column x = w - d
+  // pattern statistics per unclamped centre column x = w - d; windows x <= -(bs-1-bs/2) are all the same
+  // fully clamped window and are listed once
   if (per_frame) {
     if (in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
-    st = launch_prepass(in1, (long)H * W, frames * C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
+    st = launch_prepass(in1, (long)H * W, frames * C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, ws.counters + 1,
+                        ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, stream);
   } else {
-    st = launch_prepass(in1, (long)H * W, C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, stream);
+    st = launch_prepass(in1, (long)H * W, C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, ws.counters + 1, ws.flag_b,
+                        -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, stream);
   }
   if (st) return st;
   switch (bs) {
-    case 3: return launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream);
-    case 5: return launch_fast<5>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream);
-    case 7: return launch_fast<7>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream);
-    case 9: return launch_fast<9>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream);
+    case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
+    case 5: st = launch_fast<5>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
+    case 7: st = launch_fast<7>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
+    case 9: st = launch_fast<9>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
     default: return CTD_ERR_UNSUPPORTED;
   }
+  if (st) return st;
+  // reference-order recomputation of the outputs of flagged (ill-conditioned) windows; the grid drains
+  // immediately when nothing was flagged
+  const size_t lds = sizeof(float) * 4 * (3 * (size_t)bs * bs + 2 * (size_t)bs * (bs + D - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  auto fix = bs == 9 ? ncc_fixup_kernel<9> : ncc_fixup_kernel<0>;
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(fix, dim3(2048), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.m0, ws.v0, ws.m1, ws.v1,
+                     per_frame ? (long)C * H * ws.W1 : 0L, ws.Wp, ws.W1, ws.xoff, ws.counters, ws.flag_a, ws.flag_b,
+                     ws.run_vals, frames, C, H, W, D, bs);
+  CTD_LAUNCH_CHECK();
+  const size_t lds_rows = sizeof(int) * (size_t)C * H;
+  if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
+                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
 }
 
 }  // namespace ctd
