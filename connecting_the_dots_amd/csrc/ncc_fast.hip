@@ -128,16 +128,22 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
     }
     double mean = s1 / n;
     double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
-    const long o = ((long)blockIdx.z * H + h) * W_out + xi;
-    out_mean[o] = (float)(mean - (double)cval);
-    out_dev[o] = (float)sqrt(var > 0 ? var : 0.0);
-    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
-    // Window whose deviation is small against its offset from the centring constant: cov = S_ab - n*ma*mb
-    // loses accuracy to cancellation in f32.  Listed for ncc_fixup_kernel (see there).
+    // Windows whose outputs the fast kernel cannot deliver within tolerance are listed for ncc_fixup_kernel
+    // (see there):
+    //  * deviation small against the offset from the centring constant: cov = S_ab - n*ma*mb cancels in f32;
+    //  * (nearly) flat window, deviation below 2e-4 of its mean: the reference's own value is then decided by
+    //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it.  Marked by
+    //    a set sign bit in the deviation plane so that every pair it takes part in is recomputed.
     const double mc = mean - (double)cval;
+    const bool flat = 4e-8 * n * mean * mean > var;
+    const bool listed = flat || n * mc * mc > kFlagRatio * var;
+    const float dev = (float)sqrt(var > 0 ? var : 0.0);
+    const long o = ((long)blockIdx.z * H + h) * W_out + xi;
+    out_mean[o] = (float)mc;
+    out_dev[o] = flat ? -dev : dev;
+    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     const int col = xi + x_start;
-    if (n * mc * mc > kFlagRatio * var && col >= col_lo && col < col_hi)
-    {
+    if (listed && col >= col_lo && col < col_hi) {
       flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)blockIdx.z << 40) | ((unsigned long long)h << 20) |
                                          (unsigned long long)(col + 0x80000);
       if (run_rows && col == col_lo) run_rows[atomicAdd(n_runs, 1u)] = ((unsigned long long)blockIdx.z << 20) | (unsigned long long)h;
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
 constexpr float kPairLimit = 8.f;
 
 __device__ inline float cond_factor(float mean_c, float dev, float n) {
+  if (__float_as_int(dev) < 0) return INFINITY;          // flat window (sign bit set by the pre-pass)
   const float num = n * mean_c * mean_c, var = dev * dev;
   return num > 0.f ? 1.f + num / var : 1.f;              // var == 0 with an offset: +inf
 }

@@ -115,3 +115,37 @@ def test_fast_argmax_kinect_bit_parity(te, oracle):
     pat_l, _ = oracle.lcn(pat[None, None], 5, 0.05)
     idx, best = te.xcorrvol_argmax(dev(ir_l[0]), dev(pat_l[0]), 128, 9, algo="fast")
     assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["kin_argmax"])
+
+
+@pytest.mark.parametrize("C,per_frame", [(1, False), (2, False), (1, True)])
+def test_fast_ill_conditioned_windows_are_recomputed(te, oracle, C, per_frame):
+    """Flat regions, windows clamped onto a flat border column and smooth backgrounds with a DC offset make
+    cov = S_ab - n*ma*mb cancel in f32; the fast path lists such windows and recomputes their outputs in
+    reference order (ncc_fixup_kernel), so the tolerance holds for any input, not only LCN'd frames."""
+    rs = np.random.RandomState(17 + C)
+    N, H, W, D, bs = 2, 40, 96, 40, 9
+    yy, xx = np.mgrid[0:H, 0:W]
+    bg = (100 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.float32)
+    a = (rs.rand(N, C, H, W) * 8 + bg).astype(np.float32)
+    a[:, :, 5:22, 30:60] = 0.25                      # exactly flat block: sigma0 == 0 windows
+    b = (rs.rand(N if per_frame else 1, C, H, W) * 20 + 0.6 * bg).astype(np.float32)
+    b[:, :, 10:30, 0:3] = 7.0                        # flat left border: the fully clamped run x <= -4 is degenerate
+    b[:, :, 24:38, 50:70] = 0.0                      # flat interior block
+    bb = dev(b) if per_frame else dev(b[0])
+    vol = te.xcorrvol_batch(dev(a), bb, D, bs, algo="fast").cpu().numpy()
+    for f in range(N):
+        ref = oracle.xcorrvol(a[f], b[f if per_frame else 0], D, bs, nthreads=8)
+        assert_close(vol[f], ref, what="frame %d" % f)
+    if C == 1:
+        idx, best = te.xcorrvol_argmax(dev(a), bb, D, bs, algo="fast")
+        idx_e, best_e = te.xcorrvol_argmax(dev(a), bb, D, bs, algo="exact")
+        assert torch.equal(idx, idx_e)
+
+
+def test_fast_constant_images(te, oracle):
+    """every window flagged: the whole volume comes out of the reference-order fix-up"""
+    a = np.full((1, 1, 24, 64), 0.5, np.float32)
+    b = np.full((1, 24, 64), 0.25, np.float32)
+    b[0, 10, 20] = 1.0
+    vol = te.xcorrvol_batch(dev(a), dev(b), 16, 9, algo="fast")[0].cpu().numpy()
+    assert np.array_equal(vol, oracle.xcorrvol(a[0], b, 16, 9))
