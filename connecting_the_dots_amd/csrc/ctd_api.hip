@@ -180,6 +180,7 @@ static bool photo_shape_ok(int B, int C, int H, int W, int bs, int type) {
   }
 CTD_PHOTO_ENTRY(f32, float)
 CTD_PHOTO_ENTRY(f64, double)
+CTD_PHOTO_ENTRY(fast_f32, float)
 #undef CTD_PHOTO_ENTRY
 
 int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,

@@ -42,6 +42,12 @@ int photometric_bwd_f64(const double* es, const double* ta, const double* go, do
 int costvol_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W, int D,
                 int bs, int type, float eps, hipStream_t stream);
 
+// photometric_fast.hip
+int photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,
+                             float eps, hipStream_t s);
+int photometric_bwd_fast_f32(const float* es, const float* ta, const float* go, float* gi, int B, int C, int H, int W,
+                             int bs, int type, float eps, hipStream_t s);
+
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 

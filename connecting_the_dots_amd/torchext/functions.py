@@ -283,18 +283,30 @@ def _photo_args(es, ta):
     return _same_device(es, ta)
 
 
+def _photo_fast(es, block_size, algo):
+    """algo 'fast' = tolerance-level kernels (f32, odd block sizes up to 9); anything else they do not cover
+    runs the reference-order kernels."""
+    algo = algo or os.environ.get("CTD_PHOTO_ALGO", "exact")
+    if algo not in _ALGOS:
+        raise RuntimeError("unknown algo %r" % (algo,))
+    return algo == "fast" and es.dtype == torch.float32 and int(block_size) in (3, 5, 7, 9)
+
+
 class PhotometricLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, es, ta, block_size, type, eps):
+    def forward(ctx, es, ta, block_size, type, eps, algo=None):
         dev = _photo_args(es, ta)
         ctx.save_for_backward(es, ta)
         ctx.block_size = block_size
         ctx.type = type
         ctx.eps = eps
+        ctx.fast = _photo_fast(es, block_size, algo)
         B, C, H, W = es.shape
         out = torch.empty((B, 1, H, W), dtype=es.dtype, device=dev)
         L = _lib.lib()
         fn = L.ctd_photometric_fwd_f32 if es.dtype == torch.float32 else L.ctd_photometric_fwd_f64
+        if ctx.fast:
+            fn = L.ctd_photometric_fwd_fast_f32
         st = fn(_ptr(es), _ptr(ta), _ptr(out), B, C, H, W, int(block_size), int(type), float(eps), dev.index,
                 _stream(dev))
         _lib.check(st, "photometric_loss_forward")
@@ -311,22 +323,26 @@ class PhotometricLossFunction(torch.autograd.Function):
         grad_es = torch.empty_like(es)
         L = _lib.lib()
         fn = L.ctd_photometric_bwd_f32 if es.dtype == torch.float32 else L.ctd_photometric_bwd_f64
+        if ctx.fast:
+            fn = L.ctd_photometric_bwd_fast_f32
         st = fn(_ptr(es), _ptr(ta), _ptr(grad_out), _ptr(grad_es), B, C, H, W, int(ctx.block_size), int(ctx.type),
                 float(ctx.eps), dev.index, _stream(dev))
         _lib.check(st, "photometric_loss_backward")
-        return grad_es, None, None, None, None
+        return grad_es, None, None, None, None, None
 
 
 _PHOTO_TYPES = {"mse": 0, "sad": 1, "census_mse": 2, "census_sad": 3}
 
 
-def photometric_loss(es, ta, block_size, type='mse', eps=0.1):
+def photometric_loss(es, ta, block_size, type='mse', eps=0.1, algo=None):
     """[B,C,H,W] x2 -> [B,1,H,W]: mean over a block_size^2 replicate-clamped block, summed over channels, of
-    (es-ta)^2 | |es-ta| | soft-census squared / absolute difference.  Gradient flows to `es` only."""
+    (es-ta)^2 | |es-ta| | soft-census squared / absolute difference.  Gradient flows to `es` only.
+    algo (additive): 'exact' = reference operation order, bit-identical to the reference CPU build (default, or
+    env CTD_PHOTO_ALGO); 'fast' = tolerance-level kernels, ~10x faster for the census types."""
     type = type.lower()
     if type not in _PHOTO_TYPES:
         raise Exception('invalid loss type')                  # functions.py:117
-    return PhotometricLossFunction.apply(es, ta, block_size, _PHOTO_TYPES[type], eps)
+    return PhotometricLossFunction.apply(es, ta, block_size, _PHOTO_TYPES[type], eps, algo)
 
 
 def photometric_loss_pytorch(es, ta, block_size, type='mse', eps=0.1):

@@ -126,6 +126,16 @@ int ctd_photometric_fwd_f32(const float* es, const float* ta, float* out, int B,
 int ctd_photometric_bwd_f32(const float* es, const float* ta, const float* grad_out,
                             float* grad_es, int B, int C, int H, int W, int block_size, int type,
                             float eps, int device, void* stream);
+/* Tolerance-level variants (f32, odd block sizes 3/5/7/9; CTD_ERR_UNSUPPORTED otherwise): same functions with
+ * the summation order left free and v_rsq_f32 in place of the correctly rounded sqrt/divide chains;
+ * |fast - reference| <= 1e-5 |reference| + 1e-6 (for the gradient: of the gradient's scale).  The backward
+ * evaluates one term per pixel pair using K(q,p) = -K(p,q) (see photometric_fast.hip), no atomics. */
+int ctd_photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B, int C, int H,
+                                 int W, int block_size, int type, float eps, int device,
+                                 void* stream);
+int ctd_photometric_bwd_fast_f32(const float* es, const float* ta, const float* grad_out,
+                                 float* grad_es, int B, int C, int H, int W, int block_size,
+                                 int type, float eps, int device, void* stream);
 int ctd_photometric_fwd_f64(const double* es, const double* ta, double* out, int B, int C, int H,
                             int W, int block_size, int type, float eps, int device, void* stream);
 int ctd_photometric_bwd_f64(const double* es, const double* ta, const double* grad_out,

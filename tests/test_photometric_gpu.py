@@ -119,3 +119,75 @@ def test_costvol_batch_vs_oracle(te, oracle):
     vol = te.costvol(dev(im), dev(pat), 20, 9, "census_sad", 0.5).cpu().numpy()
     for f in range(2):
         assert np.array_equal(vol[f], oracle.costvol(im[f], pat[f], 20, 9, 3, 0.5, nthreads=4))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# algo='fast': tolerance-level kernels (free summation order, v_rsq_f32, pair-symmetric backward)
+# ----------------------------------------------------------------------------------------------------------
+def _grad_close(got, ref, go_scale, what):
+    """|a-b| <= 1e-5|b| + 1e-6 * (scale of the gradient): a gradient entry is a signed sum of ~2*bs^2 terms of
+    size <= go/bs^2, so its absolute rounding floor scales with go"""
+    assert_close(got, ref, rtol=1e-5, atol=1e-6 * go_scale, what=what)
+
+
+@pytest.mark.parametrize("ty", TYPES)
+@pytest.mark.parametrize("shape,bs", [((2, 1, 37, 150), 9), ((1, 3, 20, 70), 5), ((1, 1, 9, 9), 9), ((2, 2, 64, 64), 3),
+                                      ((1, 1, 5, 200), 7), ((1, 1, 1, 1), 9)])
+def test_fast_matches_oracle(te, oracle, ty, shape, bs):
+    """interior tiles, border tiles (tap multiplicities > 1), images smaller than the block, C > 1"""
+    rs = np.random.RandomState(bs + sum(shape))
+    es = rs.randn(*shape).astype(np.float32)
+    ta = (es + 0.3 * rs.randn(*shape)).astype(np.float32)
+    go = rs.rand(shape[0], 1, shape[2], shape[3]).astype(np.float32)
+    eps = 0.5
+    ref = oracle.photometric_fwd(es, ta, bs, TYPES.index(ty), eps)
+    gref = oracle.photometric_bwd(es, ta, go, bs, TYPES.index(ty), eps)
+    e = dev(es).requires_grad_(True)
+    out = te.photometric_loss(e, dev(ta), bs, ty, eps, algo="fast")
+    assert_close(out.detach().cpu().numpy(), ref, what="fwd %s" % ty)
+    out.backward(dev(go))
+    _grad_close(e.grad.cpu().numpy(), gref, 1.0, "bwd %s" % ty)
+
+
+def test_fast_golden_and_sign_ties(te):
+    """committed reference outputs; es == ta makes every census diff exactly 0 (sign 0, gradient 0) and a
+    constant offset makes diff tiny but non-zero: the sign is settled in reference arithmetic"""
+    g = golden("photometric")
+    n = 0
+    for k, (B, C, H, W, bs) in enumerate(g["cases"]):
+        if int(bs) % 2 == 0:
+            continue
+        for ty in range(4):
+            for eps in (0.1, 0.5):
+                n += 1
+                e = dev(g["es_%d" % k]).requires_grad_(True)
+                out = te.photometric_loss(e, dev(g["ta_%d" % k]), int(bs), TYPES[ty], eps, algo="fast")
+                assert_close(out.detach().cpu().numpy(), g["fwd_%d_%d_%g" % (k, ty, eps)], what="fwd %d %d" % (k, ty))
+                out.backward(dev(g["go_%d" % k]))
+                _grad_close(e.grad.cpu().numpy(), g["bwd_%d_%d_%g" % (k, ty, eps)],
+                            float(np.abs(g["go_%d" % k]).max()), "bwd %d %d %g" % (k, ty, eps))
+    assert n >= 8
+    x = dev(np.random.RandomState(0).randn(1, 1, 24, 80).astype(np.float32)).requires_grad_(True)
+    out = te.photometric_loss(x, x.detach().clone(), 9, "census_sad", 0.5, algo="fast")
+    assert float(out.abs().max()) == 0.0
+    out.backward(torch.ones_like(out))
+    assert float(x.grad.abs().max()) == 0.0
+
+
+def test_fast_full_size_properties(te):
+    """BASELINE config-2 size (16 x 432 x 512): fast == exact within tolerance on every pixel, forward and backward"""
+    torch.manual_seed(3)
+    es = torch.randn(16, 1, 432, 512, device="cuda")
+    ta = es + 0.2 * torch.randn_like(es)
+    go = torch.rand(16, 1, 432, 512, device="cuda")
+    for ty in ("census_sad", "sad"):
+        a = es.clone().requires_grad_(True)
+        b = es.clone().requires_grad_(True)
+        fa = te.photometric_loss(a, ta, 9, ty, 0.5, algo="fast")
+        fb = te.photometric_loss(b, ta, 9, ty, 0.5, algo="exact")
+        assert bool(((fa - fb).abs() <= 1e-5 * fb.abs() + 1e-6).all())
+        fa.backward(go)
+        fb.backward(go)
+        bad = (a.grad - b.grad).abs() > 1e-5 * b.grad.abs() + 1e-6
+        assert int(bad.sum()) == 0, "%s: %d of %d gradient entries out of tolerance, max %.3g" % (
+            ty, int(bad.sum()), bad.numel(), float((a.grad - b.grad).abs().max()))

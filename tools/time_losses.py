@@ -9,12 +9,13 @@ def timeit(name, fn, n=10):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    print("%-34s %8.3f ms  %8.1f Mpix/s" % (name, dt * 1e3, B * H * W / dt / 1e6), flush=True)
-for ty in ("mse", "sad", "census_mse", "census_sad"):
-    e = es.clone().requires_grad_(True)
-    timeit("photometric fwd %s" % ty, lambda: te.photometric_loss(e.detach(), ta, 9, ty, 0.5))
-    out = te.photometric_loss(e, ta, 9, ty, 0.5); go = torch.rand_like(out)
-    timeit("photometric bwd %s" % ty, lambda: torch.autograd.grad(out, e, go, retain_graph=True))
+    print("%-40s %8.3f ms  %8.1f Mpix/s" % (name, dt * 1e3, B * H * W / dt / 1e6), flush=True)
+for algo in ("exact", "fast"):
+    for ty in ("mse", "sad", "census_mse", "census_sad"):
+        e = es.clone().requires_grad_(True)
+        timeit("photometric fwd %s %s" % (ty, algo), lambda: te.photometric_loss(e.detach(), ta, 9, ty, 0.5, algo=algo))
+        out = te.photometric_loss(e, ta, 9, ty, 0.5, algo=algo); go = torch.rand_like(out)
+        timeit("photometric bwd %s %s" % (ty, algo), lambda: torch.autograd.grad(out, e, go, retain_graph=True))
 timeit("lcn", lambda: te.lcn(es, 5, 0.05))
 d = (torch.rand(B, 1, H, W, device="cuda") * 60).requires_grad_(True); edge = torch.rand(B, 1, H, W, device="cuda")
 timeit("disparity_loss fwd", lambda: te.disparity_loss(d.detach(), edge))
