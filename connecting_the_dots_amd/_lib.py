@@ -40,6 +40,9 @@ SIGNATURES = {
     "ctd_geometric_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "ctd_geometric_fwd_f32": (_c_int, [_vp] * 9 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
     "ctd_geometric_bwd_f32": (_c_int, [_vp] * 10 + [_c_int, _vp] + [_c_int] * 3 + [_c_float, _c_int, _vp]),
+    "ctd_pattern_loss_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "ctd_pattern_loss_fwd_f32": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
+    "ctd_pattern_loss_bwd_f32": (_c_int, [_vp] * 8 + [_c_int] * 4 + [_c_float, _c_int, _vp]),
     "ctd_nn_f32": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_nn_f64": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_crosscheck": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),

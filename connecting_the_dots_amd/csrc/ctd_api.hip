@@ -183,6 +183,34 @@ CTD_PHOTO_ENTRY(f64, double)
 CTD_PHOTO_ENTRY(fast_f32, float)
 #undef CTD_PHOTO_ENTRY
 
+static bool img_shape_ok(int B, int H, int W);
+
+size_t ctd_pattern_loss_workspace_bytes(int B, int H, int W) {
+  return img_shape_ok(B, H, W) ? pattern_loss_workspace_bytes(B, H, W) : 0;
+}
+
+int ctd_pattern_loss_fwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                             float* pattern_proj, float* terms, int B, int H, int W, int type, float eps,
+                             void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || H < 2 || W < 2 || type < 0 || type > 3) return CTD_ERR_INVALID_ARG;
+  if (!disp || !im || !pattern || !pattern_proj || !terms) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return pattern_loss_fwd_f32(disp, im, mask, pattern, pattern_proj, terms, B, H, W, type, eps, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+}
+
+int ctd_pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                             const float* terms, const float* grad_val, const float* grad_proj, float* grad_disp,
+                             int B, int H, int W, int type, float eps, int device, void* stream) {
+  if (!img_shape_ok(B, H, W) || H < 2 || W < 2 || type < 0 || type > 3) return CTD_ERR_INVALID_ARG;
+  if (!disp || !im || !pattern || !terms || !grad_val || !grad_disp) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return pattern_loss_bwd_f32(disp, im, mask, pattern, terms, grad_val, grad_proj, grad_disp, B, H, W, type, eps,
+                              (hipStream_t)stream);
+}
+
 int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,
                     int W, int D, int block_size, int type, float eps, int device, void* stream) {
   if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0 ||

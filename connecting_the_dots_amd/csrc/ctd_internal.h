@@ -48,6 +48,14 @@ int photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B
 int photometric_bwd_fast_f32(const float* es, const float* ta, const float* go, float* gi, int B, int C, int H, int W,
                              int bs, int type, float eps, hipStream_t s);
 
+size_t pattern_loss_workspace_bytes(int B, int H, int W);
+int pattern_loss_fwd_f32(const float* disp, const float* im, const float* mask, const float* pattern, float* proj,
+                         float* terms, int B, int H, int W, int type, float eps, void* ws, size_t ws_bytes,
+                         hipStream_t s);
+int pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                         const float* terms, const float* grad_val, const float* grad_proj, float* grad_disp, int B,
+                         int H, int W, int type, float eps, hipStream_t s);
+
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 

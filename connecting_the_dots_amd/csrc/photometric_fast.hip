@@ -55,12 +55,40 @@ __device__ inline void stage_tile(float (*dst)[kPTW + BS - 1], const float* __re
   }
 }
 
+// block loss of the pixel at tile position (tx, ty), one channel
+template <int TYPE, int BS>
+__device__ inline float fwd_pixel(const float (*sE)[kPTW + BS - 1], const float (*sT)[kPTW + BS - 1], int tx, int ty,
+                                  float eps) {
+  constexpr int HALF = BS / 2;
+  const float ec = sE[ty + HALF][tx + HALF], tc = sT[ty + HALF][tx + HALF];
+  float acc = 0.f;
+#pragma unroll 1                                         // rows rolled: a fully unrolled window hoists ~2*BS^2 LDS
+  for (int dy = 0; dy < BS; ++dy)                         // loads into registers and leaves one wave per SIMD
+#pragma unroll
+    for (int dx = 0; dx < BS; ++dx) {
+      const float e = sE[ty + dy][tx + dx], t = sT[ty + dy][tx + dx];
+      if (TYPE == 0) {
+        const float d = e - t;
+        acc = fmaf(d, d, acc);
+      } else if (TYPE == 1) {
+        acc += fabsf(e - t);
+      } else {
+        const float des = e - ec, dta = t - tc;
+        const float r1 = __builtin_amdgcn_rsqf(fmaf(des, des, eps)), r2 = __builtin_amdgcn_rsqf(fmaf(dta, dta, eps));
+        const float d2 = des * r1 - dta * r2;                  // 2 * (h(des) - h(dta))
+        if (TYPE == 2) acc = fmaf(d2, d2, acc);
+        else acc += fabsf(d2);
+      }
+    }
+  return acc * ((TYPE == 2 ? 0.25f : (TYPE == 3 ? 0.5f : 1.f)) / (float)(BS * BS));
+}
+
 template <int TYPE, int BS>
 __global__ __launch_bounds__(256) void photometric_fast_fwd_kernel(const float* __restrict__ es,
                                                                    const float* __restrict__ ta,
                                                                    float* __restrict__ out, int C, int H, int W,
                                                                    float eps) {
-  constexpr int HALF = BS / 2, TW = kPTW + BS - 1, TH = kPTH + BS - 1;
+  constexpr int TW = kPTW + BS - 1, TH = kPTH + BS - 1;
   __shared__ float sE[TH][TW], sT[TH][TW];
   const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
   const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH, n = blockIdx.z;
@@ -72,31 +100,7 @@ __global__ __launch_bounds__(256) void photometric_fast_fwd_kernel(const float* 
     stage_tile<BS>(sT, ta + ((long)n * C + c) * HW, H, W, x0, y0);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int ty = ty0 + 4 * k;
-      const float ec = sE[ty + HALF][tx + HALF], tc = sT[ty + HALF][tx + HALF];
-      float acc = 0.f;
-#pragma unroll 1                                         // rows rolled: a fully unrolled window hoists ~2*BS^2 LDS
-      for (int dy = 0; dy < BS; ++dy)                     // loads into registers and leaves one wave per SIMD
-#pragma unroll
-        for (int dx = 0; dx < BS; ++dx) {
-          const float e = sE[ty + dy][tx + dx], t = sT[ty + dy][tx + dx];
-          if (TYPE == 0) {
-            const float d = e - t;
-            acc = fmaf(d, d, acc);
-          } else if (TYPE == 1) {
-            acc += fabsf(e - t);
-          } else {
-            const float des = e - ec, dta = t - tc;
-            const float r1 = __builtin_amdgcn_rsqf(fmaf(des, des, eps)), r2 = __builtin_amdgcn_rsqf(fmaf(dta, dta, eps));
-            const float d2 = des * r1 - dta * r2;                  // 2 * (h(des) - h(dta))
-            if (TYPE == 2) acc = fmaf(d2, d2, acc);
-            else acc += fabsf(d2);
-          }
-        }
-      const float scale = (TYPE == 2 ? 0.25f : (TYPE == 3 ? 0.5f : 1.f)) / (float)(BS * BS);
-      loss[k] = fmaf(acc, scale, loss[k]);
-    }
+    for (int k = 0; k < 2; ++k) loss[k] += fwd_pixel<TYPE, BS>(sE, sT, tx, ty0 + 4 * k, eps);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -106,10 +110,10 @@ __global__ __launch_bounds__(256) void photometric_fast_fwd_kernel(const float* 
 }
 
 // gradient of the two pixels a thread owns in the staged tile; BORDER = general tap multiplicities
-template <int TYPE, int BS, bool BORDER>
+template <int TYPE, int BS, bool BORDER, typename Sink>
 __device__ inline void bwd_tile(const float (*sE)[kPTW + BS - 1], const float (*sT)[kPTW + BS - 1],
-                                const float (*sG)[kPTW + BS - 1], float* __restrict__ grad_plane, int H, int W, int x0,
-                                int y0, float eps) {
+                                const float (*sG)[kPTW + BS - 1], Sink&& sink, int H, int W, int x0, int y0,
+                                float eps) {
   constexpr int HALF = BS / 2;
   const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
 #pragma unroll
@@ -191,7 +195,7 @@ __device__ inline void bwd_tile(const float (*sE)[kPTW + BS - 1], const float (*
     if (TYPE == 0) g = 2.f * (eq - tq) * acc / (float)(BS * BS);
     else if (TYPE == 1) g = (eq < tq ? -acc : (eq > tq ? acc : 0.f)) / (float)(BS * BS);
     else g = acc * (0.5f * eps / (float)(BS * BS));
-    grad_plane[(long)qy * W + qx] = g;
+    sink(qx, qy, g);
   }
 }
 
@@ -215,8 +219,9 @@ __global__ __launch_bounds__(256) void photometric_fast_bwd_kernel(const float* 
     stage_tile<BS>(sT, ta + ((long)n * C + c) * HW, H, W, x0, y0);
     __syncthreads();
     float* plane = grad_in + ((long)n * C + c) * HW;
-    if (interior) bwd_tile<TYPE, BS, false>(sE, sT, sG, plane, H, W, x0, y0, eps);
-    else bwd_tile<TYPE, BS, true>(sE, sT, sG, plane, H, W, x0, y0, eps);
+    auto sink = [&](int qx, int qy, float g) { plane[(long)qy * W + qx] = g; };
+    if (interior) bwd_tile<TYPE, BS, false>(sE, sT, sG, sink, H, W, x0, y0, eps);
+    else bwd_tile<TYPE, BS, true>(sE, sT, sG, sink, H, W, x0, y0, eps);
   }
 }
 
@@ -253,6 +258,211 @@ static int dispatch_fast(bool bwd, const float* es, const float* ta, const float
     case 9: return dispatch_type<9>(bwd, type, es, ta, go, dst, B, C, H, W, eps, s);
     default: return CTD_ERR_UNSUPPORTED;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused pattern similarity loss: RectifiedPatternSimilarityLoss.tforward,
+// /root/reference/model/networks.py:358-378, as one forward and one backward kernel.
+//   u1 = u - disp; gx = 2*(u1/(W-1) - 0.5); gy = 2*(v/(H-1) - 0.5)                       (:362-369)
+//   pattern_proj = grid_sample(pattern, (gx, gy), bilinear, border, align_corners=False)   (:371)
+//   diff = photometric_loss(pattern_proj, im, 9, type, eps); val = sum(mask*diff)/sum(mask) (:376-377)
+// The warped pattern is sampled straight into the LDS tile (halo included: the block loss reads
+// replicate-clamped taps of pattern_proj, i.e. the sample at the clamped pixel); it is written once because
+// the module returns it.  Backward recomputes the tile, runs the pair-symmetric block-loss backward and
+// applies d pattern_proj / d disp = -(W/(W-1)) * d/dix of the bilinear interpolant (0 where ATen clips).
+// ------------------------------------------------------------------------------------------------------
+struct WarpSample {
+  float value, d_ddisp;
+};
+
+// ATen grid_sampler_2d, bilinear / border / align_corners=false, for the grid networks.py builds
+__device__ inline WarpSample warp_pattern(const float* __restrict__ pat, int H, int W, int x, int y, float disp) {
+  const float u1 = (float)x - disp;
+  const float gx = 2.f * (u1 / (float)(W - 1) - 0.5f), gy = 2.f * ((float)y / (float)(H - 1) - 0.5f);
+  float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;   // unnormalize
+  // clip_coordinates_set_grad: gradient 0 at and beyond the borders
+  float gmul = 1.f;
+  if (ix <= 0.f) { ix = 0.f; gmul = 0.f; }
+  else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); gmul = 0.f; }
+  iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+  const bool xin = x1 <= W - 1, yin = y1 <= H - 1;      // x0, y0 are inside after clipping
+  const float p00 = pat[(long)y0 * W + x0];
+  const float p01 = xin ? pat[(long)y0 * W + x1] : 0.f;
+  const float p10 = yin ? pat[(long)y1 * W + x0] : 0.f;
+  const float p11 = (xin && yin) ? pat[(long)y1 * W + x1] : 0.f;
+  WarpSample r;
+  r.value = p00 * (wx0 * wy0) + p01 * (wx1 * wy0) + p10 * (wx0 * wy1) + p11 * (wx1 * wy1);
+  const float dv_dix = (p01 - p00) * wy0 + (p11 - p10) * wy1;
+  // d ix / d gx = W/2, d gx / d u1 = 2/(W-1), d u1 / d disp = -1
+  r.d_ddisp = -gmul * dv_dix * ((float)W / (float)(W - 1));
+  return r;
+}
+
+template <int BS>
+__device__ inline void stage_warped(float (*dst)[kPTW + BS - 1], const float* __restrict__ pat,
+                                    const float* __restrict__ disp, int H, int W, int x0, int y0) {
+  constexpr int HALF = BS / 2, TW = kPTW + BS - 1, TH = kPTH + BS - 1;
+  for (int i = threadIdx.x; i < TW * TH; i += 256) {
+    const int r = i / TW, c = i - r * TW;
+    const int y = clampi(y0 + r - HALF, 0, H - 1), x = clampi(x0 + c - HALF, 0, W - 1);
+    dst[r][c] = warp_pattern(pat, H, W, x, y, disp[(long)y * W + x]).value;
+  }
+}
+
+// partials[block] = (sum mask*diff, sum mask) over the block's pixels, fixed-order tree
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_fwd_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ im,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ pattern,
+                                                               float* __restrict__ proj_out,
+                                                               float2* __restrict__ partials, int H, int W,
+                                                               float eps) {
+  constexpr int TW = kPTW + BS - 1, TH = kPTH + BS - 1, HALF = BS / 2;
+  __shared__ float sE[TH][TW], sT[TH][TW];
+  __shared__ float2 red[256];
+  const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH, n = blockIdx.z;
+  const long HW = (long)H * W;
+  stage_warped<BS>(sE, pattern, disp + (long)n * HW, H, W, x0, y0);
+  stage_tile<BS>(sT, im + (long)n * HW, H, W, x0, y0);
+  __syncthreads();
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ty = ty0 + 4 * k, x = x0 + tx, y = y0 + ty;
+    if (x < W && y < H) {
+      const float diff = fwd_pixel<TYPE, BS>(sE, sT, tx, ty, eps);
+      const long o = (long)n * HW + (long)y * W + x;
+      const float m = mask ? mask[o] : 1.f;
+      acc.x = fmaf(m, diff, acc.x);
+      acc.y += m;
+      proj_out[o] = sE[ty + HALF][tx + HALF];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int stride = 128; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      red[threadIdx.x].x += red[threadIdx.x + stride].x;
+      red[threadIdx.x].y += red[threadIdx.x + stride].y;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[((long)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
+}
+
+// terms[0] = numerator, terms[1] = denominator, terms[2] = numerator / denominator; one workgroup, fixed order
+__global__ __launch_bounds__(256) void pattern_loss_finish_kernel(const float2* __restrict__ partials, long n,
+                                                                  float* __restrict__ terms) {
+  __shared__ double rx[256], ry[256];
+  double ax = 0, ay = 0;
+  for (long i = threadIdx.x; i < n; i += 256) { ax += (double)partials[i].x; ay += (double)partials[i].y; }
+  rx[threadIdx.x] = ax;
+  ry[threadIdx.x] = ay;
+  __syncthreads();
+  for (int stride = 128; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) { rx[threadIdx.x] += rx[threadIdx.x + stride]; ry[threadIdx.x] += ry[threadIdx.x + stride]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    terms[0] = (float)rx[0];
+    terms[1] = (float)ry[0];
+    terms[2] = (float)rx[0] / (float)ry[0];
+  }
+}
+
+// grad_disp = d val / d disp for val = terms[0] / terms[1]:  go[p] = grad_val * mask[p] / terms[1]
+// (+ optionally grad_proj, the gradient arriving at the returned pattern_proj)
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_bwd_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ im,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ pattern,
+                                                               const float* __restrict__ terms,
+                                                               const float* __restrict__ grad_val,
+                                                               const float* __restrict__ grad_proj,
+                                                               float* __restrict__ grad_disp, int H, int W,
+                                                               float eps) {
+  constexpr int HALF = BS / 2, TW = kPTW + BS - 1, TH = kPTH + BS - 1;
+  __shared__ float sE[TH][TW], sT[TH][TW], sG[TH][TW];
+  const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH, n = blockIdx.z;
+  const long HW = (long)H * W;
+  const float scale = grad_val[0] / terms[1];
+  const float* dsp = disp + (long)n * HW;
+  stage_warped<BS>(sE, pattern, dsp, H, W, x0, y0);
+  stage_tile<BS>(sT, im + (long)n * HW, H, W, x0, y0);
+  if (mask) {
+    stage_tile<BS>(sG, mask + (long)n * HW, H, W, x0, y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TW * TH; i += 256) (&sG[0][0])[i] *= scale;
+  } else {
+    for (int i = threadIdx.x; i < TW * TH; i += 256) (&sG[0][0])[i] = scale;
+  }
+  __syncthreads();
+  const bool interior = x0 >= 2 * HALF && y0 >= 2 * HALF && x0 + kPTW - 1 <= W - 1 - 2 * HALF &&
+                        y0 + kPTH - 1 <= H - 1 - 2 * HALF;
+  auto sink = [&](int qx, int qy, float g) {
+    const long o = (long)qy * W + qx;
+    if (grad_proj) g += grad_proj[(long)n * HW + o];
+    grad_disp[(long)n * HW + o] = g * warp_pattern(pattern, H, W, qx, qy, dsp[o]).d_ddisp;
+  };
+  if (interior) bwd_tile<TYPE, BS, false>(sE, sT, sG, sink, H, W, x0, y0, eps);
+  else bwd_tile<TYPE, BS, true>(sE, sT, sG, sink, H, W, x0, y0, eps);
+}
+
+size_t pattern_loss_workspace_bytes(int B, int H, int W) {
+  return sizeof(float2) * (size_t)B * ceil_div(H, kPTH) * ceil_div(W, kPTW);
+}
+
+template <int TYPE>
+static int pattern_loss_launch(bool bwd, const float* disp, const float* im, const float* mask, const float* pattern,
+                               float* proj, float* terms, const float* grad_val, const float* grad_proj,
+                               float* grad_disp, int B, int H, int W, float eps, void* ws, hipStream_t stream) {
+  const dim3 grid(ceil_div(W, kPTW), ceil_div(H, kPTH), B);
+  if (!bwd) {
+    float2* partials = (float2*)ws;
+    hipLaunchKernelGGL((pattern_loss_fwd_kernel<TYPE, 9>), grid, dim3(256), 0, stream, disp, im, mask, pattern, proj, partials,
+                       H, W, eps);
+    CTD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pattern_loss_finish_kernel, dim3(1), dim3(256), 0, stream, partials,
+                       (long)grid.x * grid.y * grid.z, terms);
+  } else {
+    hipLaunchKernelGGL((pattern_loss_bwd_kernel<TYPE, 9>), grid, dim3(256), 0, stream, disp, im, mask, pattern, terms,
+                       grad_val, grad_proj, grad_disp, H, W, eps);
+  }
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+static int pattern_loss_dispatch(bool bwd, int type, const float* disp, const float* im, const float* mask,
+                                 const float* pattern, float* proj, float* terms, const float* grad_val,
+                                 const float* grad_proj, float* grad_disp, int B, int H, int W, float eps, void* ws,
+                                 hipStream_t s) {
+  switch (type) {
+    case 0: return pattern_loss_launch<0>(bwd, disp, im, mask, pattern, proj, terms, grad_val, grad_proj, grad_disp, B, H, W, eps, ws, s);
+    case 1: return pattern_loss_launch<1>(bwd, disp, im, mask, pattern, proj, terms, grad_val, grad_proj, grad_disp, B, H, W, eps, ws, s);
+    case 2: return pattern_loss_launch<2>(bwd, disp, im, mask, pattern, proj, terms, grad_val, grad_proj, grad_disp, B, H, W, eps, ws, s);
+    case 3: return pattern_loss_launch<3>(bwd, disp, im, mask, pattern, proj, terms, grad_val, grad_proj, grad_disp, B, H, W, eps, ws, s);
+    default: return CTD_ERR_INVALID_ARG;
+  }
+}
+
+int pattern_loss_fwd_f32(const float* disp, const float* im, const float* mask, const float* pattern, float* proj,
+                         float* terms, int B, int H, int W, int type, float eps, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+  if (!ws || ws_bytes < pattern_loss_workspace_bytes(B, H, W)) return CTD_ERR_WORKSPACE;
+  return pattern_loss_dispatch(false, type, disp, im, mask, pattern, proj, terms, nullptr, nullptr, nullptr, B, H, W, eps,
+                               ws, s);
+}
+int pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                         const float* terms, const float* grad_val, const float* grad_proj, float* grad_disp, int B,
+                         int H, int W, int type, float eps, hipStream_t s) {
+  return pattern_loss_dispatch(true, type, disp, im, mask, pattern, nullptr, const_cast<float*>(terms), grad_val, grad_proj,
+                               grad_disp, B, H, W, eps, nullptr, s);
 }
 
 int photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,

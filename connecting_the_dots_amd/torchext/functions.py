@@ -345,6 +345,64 @@ def photometric_loss(es, ta, block_size, type='mse', eps=0.1, algo=None):
     return PhotometricLossFunction.apply(es, ta, block_size, _PHOTO_TYPES[type], eps, algo)
 
 
+class PatternLossFunction(torch.autograd.Function):
+    """Additive: the whole of RectifiedPatternSimilarityLoss.tforward (networks.py:358-378) as one
+    forward and one backward kernel -- warp, block loss (block 9), masked mean.  Tolerance level (fast kernels).
+    Returns (val, pattern_proj, terms) with terms = [sum(mask*diff), sum(mask), val] for cross-rank reduction."""
+
+    @staticmethod
+    def forward(ctx, disp, im, mask, pattern, type, eps):
+        for t, name in ((disp, "disp"), (im, "im"), (pattern, "pattern")) + (((mask, "mask"),) if mask is not None else ()):
+            _check(t, name, (torch.float32,))
+        dev = _same_device(disp, im, pattern, *(() if mask is None else (mask,)))
+        if disp.dim() != 4 or disp.shape[1] != 1 or im.shape != disp.shape or (mask is not None and mask.shape != disp.shape):
+            raise RuntimeError("pattern_loss expects disp, im (and mask) of the same [B,1,H,W] shape")
+        B, _, H, W = disp.shape
+        if pattern.numel() != H * W:
+            raise RuntimeError("pattern_loss expects a single-channel pattern with H*W elements")
+        L = _lib.lib()
+        proj = torch.empty_like(disp)
+        terms = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = _workspace(L.ctd_pattern_loss_workspace_bytes(B, H, W), dev)
+        st = L.ctd_pattern_loss_fwd_f32(_ptr(disp), _ptr(im), _ptr(mask), _ptr(pattern), _ptr(proj), _ptr(terms), B, H, W,
+                                        int(type), float(eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+        _lib.check(st, "pattern_loss_forward")
+        ctx.save_for_backward(disp, im, pattern, terms, *(() if mask is None else (mask,)))
+        ctx.has_mask = mask is not None
+        ctx.type, ctx.eps = int(type), float(eps)
+        return terms[2].clone(), proj, terms
+
+    @staticmethod
+    def backward(ctx, grad_val, grad_proj, grad_terms):
+        saved = ctx.saved_tensors
+        disp, im, pattern, terms = saved[:4]
+        mask = saved[4] if ctx.has_mask else None
+        dev = disp.device
+        B, _, H, W = disp.shape
+        # the kernel applies go[p] = gv * mask[p] / den; gradients arriving at the numerator (cross-rank ratio of
+        # sums, sharding.reduce_ratio) or at terms[2] fold into the same scalar.  den does not depend on disp.
+        gv = torch.zeros(1, dtype=torch.float32, device=dev)
+        if grad_val is not None:
+            gv = gv + grad_val.reshape(1)
+        if grad_terms is not None:
+            gv = gv + grad_terms[2:3] + grad_terms[0:1] * terms[1:2]
+        gp = grad_proj.contiguous() if grad_proj is not None else None
+        grad_disp = torch.empty_like(disp)
+        st = _lib.lib().ctd_pattern_loss_bwd_f32(_ptr(disp), _ptr(im), _ptr(mask), _ptr(pattern), _ptr(terms), _ptr(gv),
+                                                 _ptr(gp), _ptr(grad_disp), B, H, W, ctx.type, ctx.eps, dev.index,
+                                                 _stream(dev))
+        _lib.check(st, "pattern_loss_backward")
+        return grad_disp, None, None, None, None, None
+
+
+def pattern_loss(disp, im, mask, pattern, type='census_sad', eps=0.5):
+    """Fused pattern similarity loss: (val, pattern_proj, terms); gradient flows to `disp` only."""
+    type = type.lower()
+    if type not in _PHOTO_TYPES:
+        raise Exception('invalid loss type')
+    return PatternLossFunction.apply(disp, im, mask, pattern, _PHOTO_TYPES[type], eps)
+
+
 def photometric_loss_pytorch(es, ta, block_size, type='mse', eps=0.1):
     """Stock-PyTorch formulation of the same loss (replicate pad + unfold), kept as the independent
     second opinion the reference ships next to its kernels (functions.py:120-147)."""

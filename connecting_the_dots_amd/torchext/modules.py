@@ -67,6 +67,12 @@ class RectifiedPatternSimilarityLoss(torch.nn.Module):
         dev = disp0.device
         self.pattern, self.u0, self.v0 = self.pattern.to(dev), self.u0.to(dev), self.v0.to(dev)
         B = disp0.shape[0]
+        if self._fused(disp0, im, std):
+            # algo='fast': warp + block loss + masked sums in one kernel each way (photometric_fast.hip)
+            _, pattern_proj, terms = pattern_loss(disp0.contiguous(), im.contiguous(),  # noqa: F405
+                                                  None if std is None else std.contiguous(), self.pattern,
+                                                  self.loss_type, self.loss_eps)
+            return terms[0], terms[1], pattern_proj
         u1 = self.u0 - disp0.contiguous().view(B, self.im_height, self.im_width)
         gx = 2 * (u1 / (self.im_width - 1) - 0.5)
         gy = (2 * (self.v0 / (self.im_height - 1) - 0.5)).expand(B, -1, -1)
@@ -80,7 +86,20 @@ class RectifiedPatternSimilarityLoss(torch.nn.Module):
                                 algo=self.algo)
         return (mask * diff).sum(), mask.sum(), pattern_proj
 
+    def _fused(self, disp0, im, std):
+        import os
+        algo = self.algo or os.environ.get("CTD_PHOTO_ALGO", "exact")
+        return (algo == "fast" and disp0.dtype == torch.float32 and disp0.dim() == 4 and disp0.shape[1] == 1
+                and im.shape == disp0.shape and (std is None or std.shape == disp0.shape)
+                and not im.requires_grad and (std is None or not std.requires_grad))
+
     def forward(self, disp0, im, std=None):
+        if self._fused(disp0, im, std):
+            self.pattern = self.pattern.to(disp0.device)
+            val, pattern_proj, _ = pattern_loss(disp0.contiguous(), im.contiguous(),  # noqa: F405
+                                                None if std is None else std.contiguous(), self.pattern,
+                                                self.loss_type, self.loss_eps)
+            return val, pattern_proj
         num, den, pattern_proj = self.terms(disp0, im, std)
         return num / den, pattern_proj
 

@@ -206,6 +206,27 @@ int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float*
                           void* stream);
 
 /* --------------------------------------------------------------------------------------
+ * Fused pattern similarity loss (tolerance level, f32, block 9): RectifiedPatternSimilarityLoss.tforward,
+ * model/networks.py:358-378 -- warp of the reference pattern by the predicted disparity
+ * (grid_sample bilinear / border / align_corners=False on the grid of :362-369), block photometric
+ * loss against the image (:376) and masked mean (:377) in one forward and one backward kernel.
+ *   disp, im [B][1][H][W]; mask [B][1][H][W] or NULL (= ones); pattern [H][W] shared by the batch
+ *   pattern_proj [B][1][H][W] (written); terms[3] (device) = { sum(mask*diff), sum(mask), their ratio }
+ *   backward: grad_val (device scalar, d/d terms[2]), grad_proj [B][1][H][W] or NULL -> grad_disp
+ * Workspace (forward only): ctd_pattern_loss_workspace_bytes().  The reduction is a fixed-order
+ * tree: bitwise reproducible run to run.
+ * -------------------------------------------------------------------------------------- */
+size_t ctd_pattern_loss_workspace_bytes(int B, int H, int W);
+int ctd_pattern_loss_fwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                             float* pattern_proj, float* terms, int B, int H, int W, int type,
+                             float eps, void* workspace, size_t workspace_bytes, int device,
+                             void* stream);
+int ctd_pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, const float* pattern,
+                             const float* terms, const float* grad_val, const float* grad_proj,
+                             float* grad_disp, int B, int H, int W, int type, float eps, int device,
+                             void* stream);
+
+/* --------------------------------------------------------------------------------------
  * Nearest-neighbour consistency ops (integer results, bit-exact).
  * Replace nn_cuda / crosscheck_cuda / proj_nn_cuda -- torchext/ext/ext_cuda.cpp:17-68,
  * functors torchext/ext/ext.h:13-117, Python torchext/functions.py:5-56.

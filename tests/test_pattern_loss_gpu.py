@@ -30,3 +30,69 @@ def test_pattern_loss_vs_reference(name, use_std):
     assert_close(val.item(), g["val_" + tag], rtol=1e-4, atol=0, what="val " + tag)
     # the gradient w.r.t. disparity goes through grid_sample's backward (ATen, atomics): tolerance, not bits
     assert_close(disp.grad.cpu().numpy(), g["gdisp_" + tag], rtol=2e-3, atol=2e-6, what="grad " + tag)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# N1: fused kernels (algo='fast'): warp + block loss + masked mean, forward and backward
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["census_sad", "mse"])
+@pytest.mark.parametrize("use_std", [True, False])
+def test_fused_pattern_loss_vs_reference(name, use_std):
+    from connecting_the_dots_amd import torchext as te
+    g = golden("pattern_loss")
+    H, W = g["im"].shape[2:]
+    mod = te.RectifiedPatternSimilarityLoss(H, W, dev(g["pattern"]), loss_type=name, loss_eps=0.5, algo="fast")
+    disp = dev(g["disp"]).requires_grad_(True)
+    val, proj = mod(disp, dev(g["im"]), dev(g["std"]) if use_std else None)
+    val.backward()
+    tag = "%s_%d" % (name, use_std)
+    assert_close(proj.detach().cpu().numpy(), g["proj_" + tag], rtol=1e-5, atol=2e-5, what="proj " + tag)
+    assert_close(val.item(), g["val_" + tag], rtol=1e-4, atol=0, what="val " + tag)
+    assert_close(disp.grad.cpu().numpy(), g["gdisp_" + tag], rtol=2e-3, atol=2e-6, what="grad " + tag)
+
+
+def test_fused_matches_composition_at_training_size():
+    """16 x 432 x 512, census_sad, eps 0.5 (the production call, networks.py:344,376): the fused kernels against
+    the composition grid_sample + exact photometric kernels + masked mean, value / warped pattern / gradient"""
+    from connecting_the_dots_amd import torchext as te
+    torch.manual_seed(5)
+    B, H, W = 16, 432, 512
+    pattern = torch.randn(1, 3, H, W, device="cuda")
+    im = torch.randn(B, 1, H, W, device="cuda")
+    std = 0.05 + torch.rand(B, 1, H, W, device="cuda")
+    disp0 = torch.rand(B, 1, H, W, device="cuda") * 60
+    out = {}
+    for algo in ("exact", "fast"):
+        mod = te.RectifiedPatternSimilarityLoss(H, W, pattern, algo=algo)
+        d = disp0.clone().requires_grad_(True)
+        val, proj = mod(d, im, std)
+        val.backward()
+        out[algo] = (val.item(), proj.detach(), d.grad)
+    assert abs(out["fast"][0] - out["exact"][0]) <= 1e-5 * abs(out["exact"][0])
+    # bilinear weights ix - floor(ix) cancel at |ix| ~ 500 (ulp 3e-5) and multiply pattern differences of ~4
+    assert float((out["fast"][1] - out["exact"][1]).abs().max()) <= 4e-4
+    ge, gf = out["exact"][2], out["fast"][2]
+    # ATen's grid_sample backward and the exact block loss on one side, one fused kernel on the other; the warp
+    # gradient (p[x1] - p[x0]) amplifies the 1e-4 differences of the warped values
+    # gradient (p[x1] - p[x0]) amplifies the 1e-4 differences of the warped values, and a census-SAD pair whose
+    # diff lies within those 1e-4 of zero flips its sign between the two paths: a statistical bound
+    bad = (gf - ge).abs() > 2e-3 * ge.abs() + 1e-3 * float(ge.abs().max())
+    assert float(bad.float().mean()) < 1e-3, float(bad.float().mean())
+    assert float((gf - ge).abs().mean()) <= 1e-3 * float(ge.abs().mean())
+
+
+def test_fused_terms_support_cross_rank_ratio():
+    """terms() must carry gradient through the numerator so that a ratio of all-reduced sums differentiates"""
+    from connecting_the_dots_amd import torchext as te
+    torch.manual_seed(6)
+    B, H, W = 2, 40, 96
+    pattern = torch.randn(1, 1, H, W, device="cuda")
+    im, std = torch.randn(B, 1, H, W, device="cuda"), 0.1 + torch.rand(B, 1, H, W, device="cuda")
+    mod = te.RectifiedPatternSimilarityLoss(H, W, pattern, algo="fast")
+    d1 = (torch.rand(B, 1, H, W, device="cuda") * 20).requires_grad_(True)
+    d2 = d1.detach().clone().requires_grad_(True)
+    v, _ = mod(d1, im, std)
+    v.backward()
+    num, den, _ = mod.terms(d2, im, std)
+    (num / den).backward()
+    assert torch.allclose(d1.grad, d2.grad, rtol=1e-5, atol=1e-9)

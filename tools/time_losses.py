@@ -23,3 +23,10 @@ l = te.disparity_loss(d, edge)
 timeit("disparity_loss bwd", lambda: torch.autograd.grad(l, d, retain_graph=True))
 timeit("disp_to_depth fwd", lambda: te.disp_to_depth(d.detach(), 567.6 * 0.075))
 timeit("costvol census_sad D=128 (1 frame)", lambda: te.costvol(es[0, 0], ta[0, 0], 128, 9, "census_sad", 0.5), n=3)
+pattern = torch.randn(1, 3, H, W, device="cuda"); std = 0.05 + torch.rand(B, 1, H, W, device="cuda")
+for algo in ("exact", "fast"):
+    mod = te.RectifiedPatternSimilarityLoss(H, W, pattern, algo=algo)
+    dd = (torch.rand(B, 1, H, W, device="cuda") * 60).requires_grad_(True)
+    def step():
+        v, _ = mod(dd, ta, std); v.backward(); dd.grad = None
+    timeit("pattern loss fwd+bwd %s" % algo, step)
