@@ -1019,36 +1019,16 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
 #pragma unroll
       for (int k = 0; k < 6; ++k) T[j][i][k] = 0.f;
     }
-  struct RowOps {
-    float a[4], ma[4], sa[4];
-    float b[kTND][4], mb[kTND][4], sb[kTND][4];
-  };
   constexpr int kOff0 = (kTDG - 1) - WAVE * kTND;                  // span slot offset of disparity j = 0
-  auto load_row = [&](const float* pk) {
-    RowOps o;
-    lds_read4<0>(pk, lane + 1, o.a);                               // slot 4*(lane+1): own quad after the left halo
-    lds_read4<0>(pk + kTA, lane + 1, o.ma);
-    lds_read4<0>(pk + 2 * kTA, lane + 1, o.sa);
-    // disparity j = 1 sits one span slot below j = 0: both quads of values come out of the same two
-    // ds_read_b128 per array (slot offsets kOff0 - 1 .. kOff0 + 3)
-    float e[5];
-    lds_read5<kOff0 - 1>(pk + kTOffB, lane + 1, e);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o.b[1][i] = e[i]; o.b[0][i] = e[i + 1]; }
-    lds_read5<kOff0 - 1>(pk + kTOffB + kTSpanPad, lane + 1, e);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o.mb[1][i] = e[i]; o.mb[0][i] = e[i + 1]; }
-    lds_read5<kOff0 - 1>(pk + kTOffB + 2 * kTSpanPad, lane + 1, e);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o.sb[1][i] = e[i]; o.sb[0][i] = e[i + 1]; }
-    return o;
-  };
+  constexpr int kQ = (kOff0 - 1) / 4, kS = (kOff0 - 1) % 4;       // disparity j = 1 sits one span slot below j = 0:
+                                                                   // both come out of the same two aligned quads
   static_assert(kTND == 2, "two disparities per lane");
   // halo sums: lane 0 takes the left quad's suffix sums, lane 63 the right quad's prefix sums, others zero
   const int halo_side = lane == 63 ? 1 : 0;
   // applied as a multiplicative mask: hipcc 7.2 miscompiles the select form `halo_lane ? hq[i] : 0.f` here
   // (it zeroes the value for every lane < 63, lane 0 included)
   const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;
+  auto quad = [](const float* p) { return *(const f32x4*)p; };
 
   wg_barrier();                                                    // chunk 0 (operands + halos) is in LDS
   int chunk = 0;
@@ -1058,18 +1038,28 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
       const float* pk = lds + ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack;
-      const RowOps cur = load_row(pk);
-      float nma[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) nma[i] = -nf * cur.ma[i];
+      // The nine 16-byte operand reads of the row are requested together; only the first pin below (frame and
+      // pattern values) must be satisfied before the products start, the pins of the statistics quads carry a
+      // data dependency on the window sums, so the compiler is free to leave part of the reads in flight
+      // under the vertical / horizontal sums (it currently waits for six and sinks three past the products).
+      const float* own = pk + 4 * (lane + 1);                      // own quad after the left halo
+      f32x4 qa = quad(own);
+      f32x4 qb0 = quad(pk + kTOffB + 4 * (lane + 1 + kQ)), qb1 = quad(pk + kTOffB + 4 * (lane + 2 + kQ));
+      f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
+      f32x4 qm0 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 1 + kQ)), qm1 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 2 + kQ));
+      f32x4 qs0 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 1 + kQ)), qs1 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 2 + kQ));
+      asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));                    // first wait: products may start
+      const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
+      const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
       const int h = r - TAIL;
       const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
+      float me[8], se[8];
 #pragma unroll
       for (int j = 0; j < kTND; ++j) {
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = cur.a[i] * cur.b[j][i];
+          const float p = av[i] * be[kS + (1 - j) + i];            // b[j][i] = slot kOff0 - j + i
           const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
           P[j][i][u % 2] = p;
           x[i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
@@ -1084,17 +1074,25 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
         suf[2] = suf[3] + x[2];
         suf[1] = suf[2] + x[1];
         suf[0] = suf[1] + x[0];
-        float s[4];
-        window_combine4(suf, pre[3], pre, s);                       // wave-edge lanes get 0 from the missing neighbour
-        float hq[4];
-        lds_read4<0>(pk + kTOffH + ((WAVE * kTND + j) * 2) * 4, halo_side, hq);
+        float sj[4];
+        window_combine4(suf, pre[3], pre, sj);                      // wave-edge lanes get 0 from the missing neighbour
+        if (j == 0) {
+          // second wait: statistics and halo quads (the dependency on the sums keeps it after them)
+          asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
+          asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] = fmaf(halo_mask, hq[i], s[i]);
+          for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
+        }
+        // halo quad of this disparity: issued before the sums of the row's second disparity, so only the
+        // first one of a row is waited for at full latency
+        f32x4 hq = quad(pk + kTOffH + ((WAVE * kTND + j) * 2 + halo_side) * 4);
+        asm("" : "+v"(hq));
         float val[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
-          const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
+          const float sh = fmaf(halo_mask, hq[i], sj[i]);
+          const float cov = fmaf(-nf * qma[i], me[kS + (1 - j) + i], sh);
+          const float den = fmaf(qsa[i], se[kS + (1 - j) + i], 1e-8f);
           val[i] = cov * __builtin_amdgcn_rcpf(den);
         }
         const int d = d_base + j;
