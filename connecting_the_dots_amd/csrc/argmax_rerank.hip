@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
   }
 }
 
+#ifndef CTD_RESOLVE_BLOCKS
+#define CTD_RESOLVE_BLOCKS 1024
+#endif
+constexpr long kResolveBlocks = CTD_RESOLVE_BLOCKS;
+
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
                       size_t workspace_bytes, hipStream_t stream) {
@@ -226,7 +231,7 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
   const size_t lds = sizeof(float) * 4 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
   if (lds > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   const long chunks = (total + 255) / 256;
-  hipLaunchKernelGGL(argmax_resolve_kernel, dim3((unsigned)(chunks < 1024 ? chunks : 1024)), dim3(256), lds, stream, vol,
+  hipLaunchKernelGGL(argmax_resolve_kernel, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
                      in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   return CTD_OK;

@@ -26,9 +26,12 @@ __device__ inline int reflect_idx(int i, int n) {
   return i;
 }
 
+// R > 0: compile-time radius (tap loops unrolled, LDS reads pipelined); R == 0: run-time `radius_rt`
+template <int R>
 __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                               float* __restrict__ stds, int H, int W, int radius,
+                                                               float* __restrict__ stds, int H, int W, int radius_rt,
                                                                float eps) {
+  const int radius = R > 0 ? R : radius_rt;
   extern __shared__ double lds_d[];
   const int TRr = kLcnTH + 2 * radius;       // staged rows
   const int TCc = kLcnTW + 2 * radius;       // staged columns
@@ -54,12 +57,20 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
   for (int r = ty; r < TRr; r += kLcnRows) {
     const float* row = tile + r * TCc + tx;
     double s1 = 0, s2 = 0;
-    for (int k = 0; k <= 2 * radius; ++k) {
+#pragma unroll
+    for (int k = 0; k < (R > 0 ? 2 * R + 1 : 0); ++k) {
       float v = row[k];
       float v2 = v * v;                       // data**2 is an f32 tensor (networks.py:528)
       s1 += (double)v;
       s2 += (double)v2;
     }
+    if (R == 0)
+      for (int k = 0; k <= 2 * radius; ++k) {
+        float v = row[k];
+        float v2 = v * v;
+        s1 += (double)v;
+        s2 += (double)v2;
+      }
     rs1[r * kLcnTW + tx] = s1;
     rs2[r * kLcnTW + tx] = s2;
   }
@@ -71,10 +82,16 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
     const int h = h_lo + r;
     if (w >= W || h >= H) continue;
     double s1 = 0, s2 = 0;
-    for (int k = 0; k <= 2 * radius; ++k) {
+#pragma unroll
+    for (int k = 0; k < (R > 0 ? 2 * R + 1 : 0); ++k) {
       s1 += rs1[(r + k) * kLcnTW + tx];
       s2 += rs2[(r + k) * kLcnTW + tx];
     }
+    if (R == 0)
+      for (int k = 0; k <= 2 * radius; ++k) {
+        s1 += rs1[(r + k) * kLcnTW + tx];
+        s2 += rs2[(r + k) * kLcnTW + tx];
+      }
     float boxs = (float)s1, boxs2 = (float)s2;
     float avgs = boxs / cnt;
     float var = boxs2 / cnt - avgs * avgs + 1e-6f;
@@ -90,7 +107,7 @@ int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radi
   const int TRr = kLcnTH + 2 * radius, TCc = kLcnTW + 2 * radius;
   size_t lds = sizeof(double) * 2 * TRr * kLcnTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
-  auto kern = lcn_kernel;
+  auto kern = radius == 5 ? lcn_kernel<5> : lcn_kernel<0>;      // 5: the only radius the reference uses (exp_synph.py:41)
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid(ceil_div(W, kLcnTW), ceil_div(H, kLcnTH), N), block(kLcnTW, kLcnRows);

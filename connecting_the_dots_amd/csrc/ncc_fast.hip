@@ -32,6 +32,9 @@
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
 
+#ifndef CTD_FIXUP_BLOCKS
+#define CTD_FIXUP_BLOCKS 2048
+#endif
 #ifndef CTD_FIX_ABLATE
 #define CTD_FIX_ABLATE 0   // timing experiments only
 #endif
@@ -64,11 +67,13 @@ constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - c
 // out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
 // cval = f64 window mean at the image centre, recomputed identically by every workgroup.
+// BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
+template <int BSC>
 __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* __restrict__ in, long frame_stride,
                                                                   float* __restrict__ out_img,
                                                                   float* __restrict__ out_mean,
                                                                   float* __restrict__ out_dev, int H, int W,
-                                                                  int x_start, int W_out, int bs,
+                                                                  int x_start, int W_out, int bs_rt,
                                                                   unsigned* __restrict__ n_flag,
                                                                   unsigned long long* __restrict__ flag_list,
                                                                   int col_lo, int col_hi,
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
                                                                   unsigned long long* __restrict__ run_rows) {
   extern __shared__ double lds_d[];
   __shared__ double cred[kSTW * kSRows];
+  const int bs = BSC > 0 ? BSC : bs_rt;
   const int half = bs / 2;
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   double* rs1 = lds_d;
@@ -108,11 +114,18 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
   for (int r = ty; r < TRr; r += kSRows) {
     const float* row = tile + r * TCc + tx;
     double s1 = 0, s2 = 0;
-    for (int k = 0; k < bs; ++k) {
+#pragma unroll
+    for (int k = 0; k < BSC; ++k) {
       double v = (double)row[k];
       s1 += v;
       s2 += v * v;
     }
+    if (BSC == 0)
+      for (int k = 0; k < bs; ++k) {
+        double v = (double)row[k];
+        s1 += v;
+        s2 += v * v;
+      }
     rs1[r * kSTW + tx] = s1;
     rs2[r * kSTW + tx] = s2;
   }
@@ -122,10 +135,16 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
     const int h = h_lo + r;
     if (xi >= W_out || h >= H) continue;
     double s1 = 0, s2 = 0;
-    for (int k = 0; k < bs; ++k) {
+#pragma unroll
+    for (int k = 0; k < BSC; ++k) {
       s1 += rs1[(r + k) * kSTW + tx];
       s2 += rs2[(r + k) * kSTW + tx];
     }
+    if (BSC == 0)
+      for (int k = 0; k < bs; ++k) {
+        s1 += rs1[(r + k) * kSTW + tx];
+        s2 += rs2[(r + k) * kSTW + tx];
+      }
     double mean = s1 / n;
     double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
     // Windows whose outputs the fast kernel cannot deliver within tolerance are listed for ncc_fixup_kernel
@@ -1321,7 +1340,7 @@ static int launch_prepass(const float* in, long frame_stride, int nimg, float* c
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
   dim3 grid(ceil_div(W_out, kSTW), ceil_div(H, kSTH), nimg), block(kSTW, kSRows);
-  hipLaunchKernelGGL(ncc_prepass_kernel, grid, block, lds, stream, in, frame_stride, cimg, mean, dev, H, W, x_start, W_out,
+  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, in, frame_stride, cimg, mean, dev, H, W, x_start, W_out,
                      bs, n_flag, flag_list, col_lo, col_hi, n_runs, run_rows);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
@@ -1439,7 +1458,7 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   auto fix = bs == 9 ? ncc_fixup_kernel<9> : ncc_fixup_kernel<0>;
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(fix, dim3(2048), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.m0, ws.v0, ws.m1, ws.v1,
+  hipLaunchKernelGGL(fix, dim3(CTD_FIXUP_BLOCKS), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.m0, ws.v0, ws.m1, ws.v1,
                      per_frame ? (long)C * H * ws.W1 : 0L, ws.Wp, ws.W1, ws.xoff, ws.counters, ws.flag_a, ws.flag_b,
                      ws.run_vals, frames, C, H, W, D, bs);
   CTD_LAUNCH_CHECK();
