@@ -12,6 +12,14 @@ LIB_PATH = os.environ.get("CTD_HIP_LIB") or os.path.join(_PKG, "libctd_hip.so")
 _c_int, _c_long, _c_float, _c_size_t, _vp = (ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t,
                                              ctypes.c_void_p)
 
+class PatternLevel(ctypes.Structure):
+    """ctd_pattern_level of include/ctd_hip.h"""
+    _fields_ = [("disp", _vp), ("im", _vp), ("mask", _vp), ("pattern", _vp), ("pattern_proj", _vp), ("grad_proj", _vp),
+                ("grad_disp", _vp), ("B", _c_int), ("H", _c_int), ("W", _c_int)]
+
+
+_levels_p = ctypes.POINTER(PatternLevel)
+
 # name -> (restype, argtypes); mirrors include/ctd_hip.h one to one
 SIGNATURES = {
     "ctd_version": (_c_int, []),
@@ -43,6 +51,9 @@ SIGNATURES = {
     "ctd_pattern_loss_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "ctd_pattern_loss_fwd_f32": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
     "ctd_pattern_loss_bwd_f32": (_c_int, [_vp] * 8 + [_c_int] * 4 + [_c_float, _c_int, _vp]),
+    "ctd_pattern_loss_multi_workspace_bytes": (_c_size_t, [_c_int, _levels_p]),
+    "ctd_pattern_loss_multi_fwd_f32": (_c_int, [_c_int, _levels_p, _vp, _c_int, _c_float, _vp, _c_size_t, _c_int, _vp]),
+    "ctd_pattern_loss_multi_bwd_f32": (_c_int, [_c_int, _levels_p, _vp, _vp, _c_int, _c_float, _c_int, _vp]),
     "ctd_nn_f32": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_nn_f64": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_crosscheck": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),

@@ -211,6 +211,26 @@ int ctd_pattern_loss_bwd_f32(const float* disp, const float* im, const float* ma
                               (hipStream_t)stream);
 }
 
+size_t ctd_pattern_loss_multi_workspace_bytes(int n_levels, const ctd_pattern_level* levels) {
+  return pattern_loss_multi_workspace_bytes(n_levels, levels);
+}
+
+int ctd_pattern_loss_multi_fwd_f32(int n_levels, const ctd_pattern_level* levels, float* terms, int type, float eps,
+                                   void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!terms || type < 0 || type > 3) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return pattern_loss_multi_fwd_f32(n_levels, levels, terms, type, eps, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ctd_pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, const float* terms,
+                                   const float* grad_vals, int type, float eps, int device, void* stream) {
+  if (!terms || !grad_vals || type < 0 || type > 3) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return pattern_loss_multi_bwd_f32(n_levels, levels, terms, grad_vals, type, eps, (hipStream_t)stream);
+}
+
 int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,
                     int W, int D, int block_size, int type, float eps, int device, void* stream) {
   if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0 ||

@@ -56,6 +56,12 @@ int pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, 
                          const float* terms, const float* grad_val, const float* grad_proj, float* grad_disp, int B,
                          int H, int W, int type, float eps, hipStream_t s);
 
+size_t pattern_loss_multi_workspace_bytes(int n_levels, const ctd_pattern_level* levels);
+int pattern_loss_multi_fwd_f32(int n_levels, const ctd_pattern_level* levels, float* terms, int type, float eps, void* ws,
+                               size_t ws_bytes, hipStream_t stream);
+int pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, const float* terms, const float* grad_vals,
+                               int type, float eps, hipStream_t stream);
+
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 

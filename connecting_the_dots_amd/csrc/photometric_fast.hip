@@ -312,20 +312,16 @@ __device__ inline void stage_warped(float (*dst)[kPTW + BS - 1], const float* __
   }
 }
 
-// partials[block] = (sum mask*diff, sum mask) over the block's pixels, fixed-order tree
+// (sum mask*diff, sum mask) over the tile's pixels, fixed-order tree; the result is valid in thread 0
 template <int TYPE, int BS>
-__global__ __launch_bounds__(256) void pattern_loss_fwd_kernel(const float* __restrict__ disp,
-                                                               const float* __restrict__ im,
-                                                               const float* __restrict__ mask,
-                                                               const float* __restrict__ pattern,
-                                                               float* __restrict__ proj_out,
-                                                               float2* __restrict__ partials, int H, int W,
-                                                               float eps) {
+__device__ inline float2 pattern_fwd_tile(const float* __restrict__ disp, const float* __restrict__ im,
+                                          const float* __restrict__ mask, const float* __restrict__ pattern,
+                                          float* __restrict__ proj_out, int H, int W, int x0, int y0, int n,
+                                          float eps) {
   constexpr int TW = kPTW + BS - 1, TH = kPTH + BS - 1, HALF = BS / 2;
   __shared__ float sE[TH][TW], sT[TH][TW];
   __shared__ float2 red[256];
   const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH, n = blockIdx.z;
   const long HW = (long)H * W;
   stage_warped<BS>(sE, pattern, disp + (long)n * HW, H, W, x0, y0);
   stage_tile<BS>(sT, im + (long)n * HW, H, W, x0, y0);
@@ -352,7 +348,80 @@ __global__ __launch_bounds__(256) void pattern_loss_fwd_kernel(const float* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) partials[((long)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
+  return red[0];
+}
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_fwd_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ im,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ pattern,
+                                                               float* __restrict__ proj_out,
+                                                               float2* __restrict__ partials, int H, int W,
+                                                               float eps) {
+  const float2 r = pattern_fwd_tile<TYPE, BS>(disp, im, mask, pattern, proj_out, H, W, blockIdx.x * kPTW,
+                                              blockIdx.y * kPTH, blockIdx.z, eps);
+  if (threadIdx.x == 0) partials[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = r;
+}
+
+// ---- several pyramid levels in one launch (the training loop calls the loss once per scale on
+// shrinking images, exp_synph.py:107-111; the 60x80 levels are launch-bound).  The level table travels in the
+// kernel arguments; a workgroup finds its level from its linear index.
+constexpr int kMaxLevels = 8;
+struct PatternLevelDev {
+  const float *disp, *im, *mask, *pattern, *grad_proj;
+  float *proj, *grad_disp;
+  int B, H, W, tiles_x, tiles_y;
+  unsigned block_begin;                      // first workgroup (== first partial) of this level
+};
+struct PatternLevelsDev {
+  PatternLevelDev lv[kMaxLevels];
+  int n;
+};
+
+__device__ inline int find_level(const PatternLevelsDev& t, unsigned block, int& bx, int& by, int& n) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxLevels; ++k)
+    if (k < t.n && block >= t.lv[k].block_begin) l = k;
+  const unsigned local = block - t.lv[l].block_begin;
+  bx = (int)(local % t.lv[l].tiles_x);
+  by = (int)((local / t.lv[l].tiles_x) % t.lv[l].tiles_y);
+  n = (int)(local / ((unsigned)t.lv[l].tiles_x * t.lv[l].tiles_y));
+  return l;
+}
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_multi_fwd_kernel(PatternLevelsDev t, float2* __restrict__ partials,
+                                                                     float eps) {
+  int bx, by, n;
+  const int l = find_level(t, blockIdx.x, bx, by, n);
+  const PatternLevelDev& L = t.lv[l];
+  const float2 r = pattern_fwd_tile<TYPE, BS>(L.disp, L.im, L.mask, L.pattern, L.proj, L.H, L.W, bx * kPTW, by * kPTH, n, eps);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// one workgroup per level: terms[level][3]
+__global__ __launch_bounds__(256) void pattern_loss_multi_finish_kernel(PatternLevelsDev t, unsigned total_blocks,
+                                                                        const float2* __restrict__ partials,
+                                                                        float* __restrict__ terms) {
+  __shared__ double rx[256], ry[256];
+  const int l = blockIdx.x;
+  const unsigned lo = t.lv[l].block_begin, hi = l + 1 < t.n ? t.lv[l + 1].block_begin : total_blocks;
+  double ax = 0, ay = 0;
+  for (unsigned i = lo + threadIdx.x; i < hi; i += 256) { ax += (double)partials[i].x; ay += (double)partials[i].y; }
+  rx[threadIdx.x] = ax;
+  ry[threadIdx.x] = ay;
+  __syncthreads();
+  for (int stride = 128; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) { rx[threadIdx.x] += rx[threadIdx.x + stride]; ry[threadIdx.x] += ry[threadIdx.x + stride]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    terms[3 * l + 0] = (float)rx[0];
+    terms[3 * l + 1] = (float)ry[0];
+    terms[3 * l + 2] = (float)rx[0] / (float)ry[0];
+  }
 }
 
 // terms[0] = numerator, terms[1] = denominator, terms[2] = numerator / denominator; one workgroup, fixed order
@@ -378,20 +447,13 @@ __global__ __launch_bounds__(256) void pattern_loss_finish_kernel(const float2* 
 // grad_disp = d val / d disp for val = terms[0] / terms[1]:  go[p] = grad_val * mask[p] / terms[1]
 // (+ optionally grad_proj, the gradient arriving at the returned pattern_proj)
 template <int TYPE, int BS>
-__global__ __launch_bounds__(256) void pattern_loss_bwd_kernel(const float* __restrict__ disp,
-                                                               const float* __restrict__ im,
-                                                               const float* __restrict__ mask,
-                                                               const float* __restrict__ pattern,
-                                                               const float* __restrict__ terms,
-                                                               const float* __restrict__ grad_val,
-                                                               const float* __restrict__ grad_proj,
-                                                               float* __restrict__ grad_disp, int H, int W,
-                                                               float eps) {
+__device__ inline void pattern_bwd_tile(const float* __restrict__ disp, const float* __restrict__ im,
+                                        const float* __restrict__ mask, const float* __restrict__ pattern,
+                                        float scale, const float* __restrict__ grad_proj,
+                                        float* __restrict__ grad_disp, int H, int W, int x0, int y0, int n, float eps) {
   constexpr int HALF = BS / 2, TW = kPTW + BS - 1, TH = kPTH + BS - 1;
   __shared__ float sE[TH][TW], sT[TH][TW], sG[TH][TW];
-  const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH, n = blockIdx.z;
   const long HW = (long)H * W;
-  const float scale = grad_val[0] / terms[1];
   const float* dsp = disp + (long)n * HW;
   stage_warped<BS>(sE, pattern, dsp, H, W, x0, y0);
   stage_tile<BS>(sT, im + (long)n * HW, H, W, x0, y0);
@@ -412,6 +474,30 @@ __global__ __launch_bounds__(256) void pattern_loss_bwd_kernel(const float* __re
   };
   if (interior) bwd_tile<TYPE, BS, false>(sE, sT, sG, sink, H, W, x0, y0, eps);
   else bwd_tile<TYPE, BS, true>(sE, sT, sG, sink, H, W, x0, y0, eps);
+}
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_bwd_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ im,
+                                                               const float* __restrict__ mask,
+                                                               const float* __restrict__ pattern,
+                                                               const float* __restrict__ terms,
+                                                               const float* __restrict__ grad_val,
+                                                               const float* __restrict__ grad_proj,
+                                                               float* __restrict__ grad_disp, int H, int W,
+                                                               float eps) {
+  pattern_bwd_tile<TYPE, BS>(disp, im, mask, pattern, grad_val[0] / terms[1], grad_proj, grad_disp, H, W,
+                             blockIdx.x * kPTW, blockIdx.y * kPTH, blockIdx.z, eps);
+}
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void pattern_loss_multi_bwd_kernel(PatternLevelsDev t, const float* __restrict__ terms,
+                                                                     const float* __restrict__ grad_vals, float eps) {
+  int bx, by, n;
+  const int l = find_level(t, blockIdx.x, bx, by, n);
+  const PatternLevelDev& L = t.lv[l];
+  pattern_bwd_tile<TYPE, BS>(L.disp, L.im, L.mask, L.pattern, grad_vals[l] / terms[3 * l + 1], L.grad_proj, L.grad_disp,
+                             L.H, L.W, bx * kPTW, by * kPTH, n, eps);
 }
 
 size_t pattern_loss_workspace_bytes(int B, int H, int W) {
@@ -463,6 +549,76 @@ int pattern_loss_bwd_f32(const float* disp, const float* im, const float* mask, 
                          int H, int W, int type, float eps, hipStream_t s) {
   return pattern_loss_dispatch(true, type, disp, im, mask, pattern, nullptr, const_cast<float*>(terms), grad_val, grad_proj,
                                grad_disp, B, H, W, eps, nullptr, s);
+}
+
+static int build_levels(int n_levels, const ctd_pattern_level* levels, PatternLevelsDev& t, unsigned& total) {
+  if (n_levels < 1 || n_levels > kMaxLevels || !levels) return CTD_ERR_INVALID_ARG;
+  total = 0;
+  t.n = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    const ctd_pattern_level& s = levels[l];
+    if (s.B <= 0 || s.H < 2 || s.W < 2 || !s.disp || !s.im || !s.pattern) return CTD_ERR_INVALID_ARG;
+    PatternLevelDev& d = t.lv[l];
+    d.disp = s.disp; d.im = s.im; d.mask = s.mask; d.pattern = s.pattern; d.grad_proj = s.grad_proj;
+    d.proj = s.pattern_proj; d.grad_disp = s.grad_disp;
+    d.B = s.B; d.H = s.H; d.W = s.W;
+    d.tiles_x = ceil_div(s.W, kPTW);
+    d.tiles_y = ceil_div(s.H, kPTH);
+    d.block_begin = total;
+    const double blocks = (double)d.tiles_x * d.tiles_y * s.B;
+    if (total + blocks >= 2147483648.0) return CTD_ERR_INVALID_ARG;
+    total += (unsigned)blocks;
+  }
+  return CTD_OK;
+}
+
+size_t pattern_loss_multi_workspace_bytes(int n_levels, const ctd_pattern_level* levels) {
+  PatternLevelsDev t;
+  unsigned total = 0;
+  if (build_levels(n_levels, levels, t, total)) return 0;
+  return sizeof(float2) * (size_t)total;
+}
+
+int pattern_loss_multi_fwd_f32(int n_levels, const ctd_pattern_level* levels, float* terms, int type, float eps, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
+  PatternLevelsDev t;
+  unsigned total = 0;
+  int st = build_levels(n_levels, levels, t, total);
+  if (st) return st;
+  for (int l = 0; l < n_levels; ++l)
+    if (!levels[l].pattern_proj) return CTD_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < sizeof(float2) * (size_t)total) return CTD_ERR_WORKSPACE;
+  float2* partials = (float2*)ws;
+  switch (type) {
+    case 0: hipLaunchKernelGGL((pattern_loss_multi_fwd_kernel<0, 9>), dim3(total), dim3(256), 0, stream, t, partials, eps); break;
+    case 1: hipLaunchKernelGGL((pattern_loss_multi_fwd_kernel<1, 9>), dim3(total), dim3(256), 0, stream, t, partials, eps); break;
+    case 2: hipLaunchKernelGGL((pattern_loss_multi_fwd_kernel<2, 9>), dim3(total), dim3(256), 0, stream, t, partials, eps); break;
+    case 3: hipLaunchKernelGGL((pattern_loss_multi_fwd_kernel<3, 9>), dim3(total), dim3(256), 0, stream, t, partials, eps); break;
+    default: return CTD_ERR_INVALID_ARG;
+  }
+  CTD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pattern_loss_multi_finish_kernel, dim3(n_levels), dim3(256), 0, stream, t, total, partials, terms);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, const float* terms, const float* grad_vals,
+                               int type, float eps, hipStream_t stream) {
+  PatternLevelsDev t;
+  unsigned total = 0;
+  int st = build_levels(n_levels, levels, t, total);
+  if (st) return st;
+  for (int l = 0; l < n_levels; ++l)
+    if (!levels[l].grad_disp) return CTD_ERR_INVALID_ARG;
+  switch (type) {
+    case 0: hipLaunchKernelGGL((pattern_loss_multi_bwd_kernel<0, 9>), dim3(total), dim3(256), 0, stream, t, terms, grad_vals, eps); break;
+    case 1: hipLaunchKernelGGL((pattern_loss_multi_bwd_kernel<1, 9>), dim3(total), dim3(256), 0, stream, t, terms, grad_vals, eps); break;
+    case 2: hipLaunchKernelGGL((pattern_loss_multi_bwd_kernel<2, 9>), dim3(total), dim3(256), 0, stream, t, terms, grad_vals, eps); break;
+    case 3: hipLaunchKernelGGL((pattern_loss_multi_bwd_kernel<3, 9>), dim3(total), dim3(256), 0, stream, t, terms, grad_vals, eps); break;
+    default: return CTD_ERR_INVALID_ARG;
+  }
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
 }
 
 int photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,

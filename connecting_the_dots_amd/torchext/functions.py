@@ -403,6 +403,87 @@ def pattern_loss(disp, im, mask, pattern, type='census_sad', eps=0.5):
     return PatternLossFunction.apply(disp, im, mask, pattern, _PHOTO_TYPES[type], eps)
 
 
+class PatternLossMultiFunction(torch.autograd.Function):
+    """Additive: the pattern similarity loss of all pyramid levels in one forward and one backward
+    launch.  apply(type, eps, n, disp_0..disp_{n-1}, im_0.., mask_0.. (None allowed), pattern_0..) ->
+    (vals [n], terms [n,3], proj_0..proj_{n-1})."""
+
+    @staticmethod
+    def _levels(n, disps, ims, masks, patterns, projs=None, grad_projs=None, grad_disps=None):
+        arr = (_lib.PatternLevel * n)()
+        for l in range(n):
+            B, _, H, W = disps[l].shape
+            arr[l] = _lib.PatternLevel(_ptr(disps[l]), _ptr(ims[l]), _ptr(masks[l]), _ptr(patterns[l]),
+                                       _ptr(projs[l]) if projs else None, _ptr(grad_projs[l]) if grad_projs else None,
+                                       _ptr(grad_disps[l]) if grad_disps else None, B, H, W)
+        return arr
+
+    @staticmethod
+    def forward(ctx, type, eps, n, *tensors):
+        disps, ims, masks, patterns = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n], tensors[3 * n:4 * n]
+        for l in range(n):
+            for t, name in ((disps[l], "disp"), (ims[l], "im"), (patterns[l], "pattern")) + (
+                    ((masks[l], "mask"),) if masks[l] is not None else ()):
+                _check(t, "%s[%d]" % (name, l), (torch.float32,))
+            if disps[l].dim() != 4 or disps[l].shape[1] != 1 or ims[l].shape != disps[l].shape or (
+                    masks[l] is not None and masks[l].shape != disps[l].shape):
+                raise RuntimeError("pattern_loss_multi: level %d expects disp, im (and mask) of one [B,1,H,W] shape" % l)
+            if patterns[l].numel() != disps[l].shape[2] * disps[l].shape[3]:
+                raise RuntimeError("pattern_loss_multi: level %d pattern must have H*W elements" % l)
+        dev = _same_device(*disps, *ims, *patterns, *[m for m in masks if m is not None])
+        L = _lib.lib()
+        projs = [torch.empty_like(d) for d in disps]
+        terms = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        levels = PatternLossMultiFunction._levels(n, disps, ims, masks, patterns, projs)
+        ws = _workspace(L.ctd_pattern_loss_multi_workspace_bytes(n, levels), dev)
+        st = L.ctd_pattern_loss_multi_fwd_f32(n, levels, _ptr(terms), int(type), float(eps), _ptr(ws), ws.numel(), dev.index,
+                                              _stream(dev))
+        _lib.check(st, "pattern_loss_multi_forward")
+        ctx.save_for_backward(terms, *disps, *ims, *patterns, *[m for m in masks if m is not None])
+        ctx.n, ctx.type, ctx.eps = n, int(type), float(eps)
+        ctx.has_mask = [m is not None for m in masks]
+        return (terms[:, 2].clone(), terms) + tuple(projs)
+
+    @staticmethod
+    def backward(ctx, grad_vals, grad_terms, *grad_projs):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        terms = saved[0]
+        disps, ims, patterns = saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:1 + 3 * n]
+        rest = list(saved[1 + 3 * n:])
+        masks = [rest.pop(0) if h else None for h in ctx.has_mask]
+        dev = terms.device
+        # gradients arriving at the numerators / ratios fold into one scalar per level (see PatternLossFunction)
+        gv = torch.zeros(n, dtype=torch.float32, device=dev)
+        if grad_vals is not None:
+            gv = gv + grad_vals
+        if grad_terms is not None:
+            gv = gv + grad_terms[:, 2] + grad_terms[:, 0] * terms[:, 1]
+        gv = gv.contiguous()
+        gps = [g.contiguous() if g is not None else None for g in grad_projs]
+        grad_disps = [torch.empty_like(d) for d in disps]
+        levels = PatternLossMultiFunction._levels(n, disps, ims, masks, patterns, None, gps, grad_disps)
+        st = _lib.lib().ctd_pattern_loss_multi_bwd_f32(n, levels, _ptr(terms), _ptr(gv), ctx.type, ctx.eps, dev.index,
+                                                       _stream(dev))
+        _lib.check(st, "pattern_loss_multi_backward")
+        return (None, None, None) + tuple(grad_disps) + (None,) * (3 * n)
+
+
+def pattern_loss_multi(disps, ims, masks, patterns, type='census_sad', eps=0.5):
+    """Fused pattern similarity loss of several pyramid levels (lists of per-level tensors; masks may hold None)
+    in one launch each way: (vals [n], terms [n,3], [pattern_proj per level])."""
+    type = type.lower()
+    if type not in _PHOTO_TYPES:
+        raise Exception('invalid loss type')
+    n = len(disps)
+    if not (len(ims) == len(masks) == len(patterns) == n) or n < 1 or n > 8:
+        raise RuntimeError("pattern_loss_multi expects 1..8 levels with one disp, im, mask and pattern each")
+    out = PatternLossMultiFunction.apply(_PHOTO_TYPES[type], eps, n, *[d.contiguous() for d in disps],
+                                         *[i.contiguous() for i in ims],
+                                         *[None if m is None else m.contiguous() for m in masks], *patterns)
+    return out[0], out[1], list(out[2:])
+
+
 def photometric_loss_pytorch(es, ta, block_size, type='mse', eps=0.1):
     """Stock-PyTorch formulation of the same loss (replicate pad + unfold), kept as the independent
     second opinion the reference ships next to its kernels (functions.py:120-147)."""

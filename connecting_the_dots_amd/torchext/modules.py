@@ -104,6 +104,26 @@ class RectifiedPatternSimilarityLoss(torch.nn.Module):
         return num / den, pattern_proj
 
 
+class MultiScalePatternSimilarityLoss(torch.nn.Module):
+    """Additive: the `RectifiedPatternSimilarityLoss` of every pyramid level (the loop of
+    model/exp_synph.py:107-111) in one forward and one backward launch.  `patterns[s]` is the LCN'd pattern of
+    scale s, [1,C,H_s,W_s]; call with lists `(disps, ims, stds)` (stds entries may be None) ->
+    `(vals [n_scales], [pattern_proj per scale])`.  Values equal the per-scale fused module's bit for bit."""
+
+    def __init__(self, patterns, loss_type='census_sad', loss_eps=0.5):
+        super().__init__()
+        self.patterns = [p.mean(dim=1, keepdim=True).contiguous() for p in patterns]
+        self.loss_type, self.loss_eps = loss_type, loss_eps
+
+    def forward(self, disps, ims, stds=None):
+        n = len(self.patterns)
+        stds = list(stds) if stds is not None else [None] * n
+        self.patterns = [p.to(disps[0].device) for p in self.patterns]
+        vals, _, projs = pattern_loss_multi(list(disps), list(ims), stds, self.patterns, self.loss_type,  # noqa: F405
+                                            self.loss_eps)
+        return vals, projs
+
+
 class DispToDepth(torch.nn.Module):
     """`networks.DispToDepth(focal_length, baseline)` (model/networks.py:313-321), one fused kernel each way."""
 

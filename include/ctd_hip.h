@@ -226,6 +226,27 @@ int ctd_pattern_loss_bwd_f32(const float* disp, const float* im, const float* ma
                              float* grad_disp, int B, int H, int W, int type, float eps, int device,
                              void* stream);
 
+/* Several pyramid levels (and any number of track frames stacked in B) in ONE forward and ONE backward launch
+ * (the reference loops over the scales in Python, model/exp_synph.py:107-111,
+ * model/exp_synphge.py:141-150).  Results per level are identical to the single-level calls.
+ *   levels[l]: tensors of level l as in ctd_pattern_loss_fwd/bwd_f32 (mask, grad_proj may be NULL;
+ *   pattern_proj is written by the forward, grad_disp by the backward); at most 8 levels.
+ *   terms [n_levels][3], grad_vals [n_levels] (device). */
+typedef struct ctd_pattern_level {
+  const float *disp, *im, *mask, *pattern;
+  float* pattern_proj;
+  const float* grad_proj;
+  float* grad_disp;
+  int B, H, W;
+} ctd_pattern_level;
+size_t ctd_pattern_loss_multi_workspace_bytes(int n_levels, const ctd_pattern_level* levels);
+int ctd_pattern_loss_multi_fwd_f32(int n_levels, const ctd_pattern_level* levels, float* terms, int type,
+                                   float eps, void* workspace, size_t workspace_bytes, int device,
+                                   void* stream);
+int ctd_pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, const float* terms,
+                                   const float* grad_vals, int type, float eps, int device,
+                                   void* stream);
+
 /* --------------------------------------------------------------------------------------
  * Nearest-neighbour consistency ops (integer results, bit-exact).
  * Replace nn_cuda / crosscheck_cuda / proj_nn_cuda -- torchext/ext/ext_cuda.cpp:17-68,

@@ -96,3 +96,28 @@ def test_fused_terms_support_cross_rank_ratio():
     num, den, _ = mod.terms(d2, im, std)
     (num / den).backward()
     assert torch.allclose(d1.grad, d2.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_multi_level_launch_equals_per_level_calls():
+    """N2: four pyramid levels (480x640 ... 60x80, as exp_synph.py trains on) in one launch each way give the
+    very same numbers as four single-level calls (same tile code, same fixed-order reductions)"""
+    from connecting_the_dots_amd import torchext as te
+    torch.manual_seed(8)
+    B = 2
+    disps, ims, stds, pats = [], [], [], []
+    for s in range(4):
+        H, W = 480 >> s, 640 >> s
+        pats.append(torch.randn(1, 1, H, W, device="cuda"))
+        ims.append(torch.randn(B, 1, H, W, device="cuda"))
+        stds.append(None if s == 3 else 0.05 + torch.rand(B, 1, H, W, device="cuda"))
+        disps.append(torch.rand(B, 1, H, W, device="cuda") * (60 >> s))
+    da = [d.clone().requires_grad_(True) for d in disps]
+    vals, terms, projs = te.pattern_loss_multi(da, ims, stds, pats, "census_sad", 0.5)
+    w = torch.tensor([1.0, 0.5, 0.25, 2.0], device="cuda")
+    (vals * w).sum().backward()
+    for s in range(4):
+        d = disps[s].clone().requires_grad_(True)
+        v, p, t = te.pattern_loss(d, ims[s], stds[s], pats[s], "census_sad", 0.5)
+        (v * w[s]).backward()
+        assert torch.equal(v, vals[s]) and torch.equal(t, terms[s]) and torch.equal(p, projs[s])
+        assert torch.equal(d.grad, da[s].grad)

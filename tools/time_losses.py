@@ -30,3 +30,22 @@ for algo in ("exact", "fast"):
     def step():
         v, _ = mod(dd, ta, std); v.backward(); dd.grad = None
     timeit("pattern loss fwd+bwd %s" % algo, step)
+# N2: the four pyramid levels of a training step (B = 8), per-level calls vs one launch each way
+Bm = 8; lv = []
+for s in range(4):
+    Hs, Ws = 480 >> s, 640 >> s
+    lv.append((torch.randn(1, 1, Hs, Ws, device="cuda"), torch.randn(Bm, 1, Hs, Ws, device="cuda"),
+               0.05 + torch.rand(Bm, 1, Hs, Ws, device="cuda"), (torch.rand(Bm, 1, Hs, Ws, device="cuda") * (60 >> s)).requires_grad_(True)))
+def per_level():
+    tot = 0
+    for p, im, st, d in lv:
+        v, _, _ = te.pattern_loss(d, im, st, p, "census_sad", 0.5); tot = tot + v
+    tot.backward()
+    for _, _, _, d in lv: d.grad = None
+def one_launch():
+    vals, _, _ = te.pattern_loss_multi([l[3] for l in lv], [l[1] for l in lv], [l[2] for l in lv], [l[0] for l in lv])
+    vals.sum().backward()
+    for _, _, _, d in lv: d.grad = None
+B = Bm; H, W = 480, 640
+timeit("4-level pattern loss, per level", per_level)
+timeit("4-level pattern loss, one launch", one_launch)
