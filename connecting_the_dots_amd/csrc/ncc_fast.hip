@@ -692,27 +692,24 @@ __device__ inline void lds_read5(const float* arr, int lane, float (&o)[5]) {
 }
 
 // out[i] = prev_lane(sp[i]) + own + next_lane(pn[i]) for the lane's 4 columns: 8 v_add_f32_dpp.
-// Every DPP add accumulates INTO a register preset to `own`: a lane whose shifted source does not exist
-// (lane 0 for wave_shr, lane 63 for wave_shl) is skipped by the hardware rather than fed a zero, so its
-// destination must already hold the right value (= a zero contribution from the missing neighbour).
+// Without bound_ctrl a lane whose shifted source does not exist (lane 0 for wave_shr, lane 63 for wave_shl) is
+// skipped by the hardware (its destination keeps the old value); with bound_ctrl:1 it reads 0, which is the
+// missing neighbour's contribution, so the three-operand form needs no preset moves.
 // One s_nop 1 covers the VALU-write -> DPP-read hazard of the operands (2 wait states).
 __device__ inline void window_combine4(const float (&sp)[4], float own, const float (&pn)[4], float (&o)[4]) {
-  o[0] = own;
-  o[1] = own;
-  o[2] = own;
-  o[3] = own;
+  // bound_ctrl:1 -- a lane whose shifted source does not exist reads 0: three-operand form, no preset moves
   asm volatile(
       "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %4, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %5, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %6, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %7, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %8, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %9, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %10, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %11, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
-      : "+&v"(o[0]), "+&v"(o[1]), "+&v"(o[2]), "+&v"(o[3])   // early clobber: inputs equal to `own` must not share a register
-      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]));
+      "v_add_f32_dpp %0, %4, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %5, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %6, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %7, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %8, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %9, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %10, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %11, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]), "v"(own));
 }
 
 template <int BS, bool ACCUM, bool VEC4, int WAVE>
