@@ -108,13 +108,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer GPUs than ranks
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("CTD_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     os.environ["CTD_NCC_ALGO"] = args.algo
     from connecting_the_dots_amd import _lib, torchext as te
@@ -150,7 +156,7 @@ def main():
     n_launch = L.ctd_kernel_timing_collect(ctypes.byref(avg_ms), ctypes.byref(cols))
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
