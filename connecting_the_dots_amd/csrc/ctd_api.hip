@@ -244,6 +244,19 @@ int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_st
                      (hipStream_t)stream);
 }
 
+int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,
+                    int W, int D, int block_size, int type, float eps, int device, void* stream) {
+  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0 ||
+      false)
+    return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!im || !pattern || !cost) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return costvol_fast_f32(im, pattern, pattern_frame_stride, cost, frames, H, W, D, block_size, type, eps,
+                     (hipStream_t)stream);
+}
+
 int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float baseline_focal, int device, void* stream) {
   if (n < 0) return CTD_ERR_INVALID_ARG;
   if (n == 0) return CTD_OK;

@@ -62,6 +62,9 @@ int pattern_loss_multi_fwd_f32(int n_levels, const ctd_pattern_level* levels, fl
 int pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, const float* terms, const float* grad_vals,
                                int type, float eps, hipStream_t stream);
 
+int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W,
+                     int D, int bs, int type, float eps, hipStream_t stream);
+
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 

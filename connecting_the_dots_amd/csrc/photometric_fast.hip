@@ -621,6 +621,124 @@ int pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, co
   return CTD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Tolerance-level SAD / census cost volume: cost[f][d] = photometric_loss(P_d, I) with
+// P_d[h][x] = P[h][clamp(x - d)] and the block loss's own replicate-clamped taps, i.e. the pattern tap of
+// output (h, x), offset (dy, dx) is P[clamp(h+dy)][clamp(clamp(x+dx) - d)].  64x8 output tiles, the image tile
+// and the pattern span of kCvChunk disparities in LDS; a thread keeps 8 disparities x 2 pixels of accumulators
+// so that the image-side soft step of a tap is computed once for 8 disparities.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kCvChunk = 32, kCvD = 8;
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void costvol_fast_kernel(const float* __restrict__ im, const float* __restrict__ pat,
+                                                           long pat_frame_stride, float* __restrict__ cost, int H, int W,
+                                                           int D, int n_chunks, float eps) {
+  constexpr int HALF = BS / 2, TW = kPTW + BS - 1, TH = kPTH + BS - 1, SW = TW + kCvChunk - 1;
+  __shared__ float sT[TH][TW], sP[TH][SW];
+  const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * kPTW, y0 = blockIdx.y * kPTH;
+  const int f = blockIdx.z / n_chunks, d0 = (blockIdx.z - f * n_chunks) * kCvChunk;
+  const long HW = (long)H * W;
+  stage_tile<BS>(sT, im + (long)f * HW, H, W, x0, y0);
+  // span column s of the tile holds pattern column (x0 - HALF - (kCvChunk - 1)) + s - d0, clamped (the second clamp)
+  const float* p = pat + (long)f * pat_frame_stride;
+  const int span_col0 = x0 - HALF - (kCvChunk - 1) - d0;
+  for (int i = threadIdx.x; i < TH * SW; i += 256) {
+    const int r = i / SW, c = i - r * SW;
+    sP[r][c] = p[(long)clampi(y0 + r - HALF, 0, H - 1) * W + clampi(span_col0 + c, 0, W - 1)];
+  }
+  __syncthreads();
+  const int x = x0 + tx;
+  // first clamp of the tap column, tile relative: tap dx of pixel x sits at image column clamp(x + dx - HALF)
+  int cx[BS];
+#pragma unroll
+  for (int dx = 0; dx < BS; ++dx) cx[dx] = clampi(x + dx - HALF, 0, W - 1) - x0 + HALF + (kCvChunk - 1);
+  for (int db = 0; db < kCvChunk; db += kCvD) {
+    if (d0 + db >= D) break;
+    float acc[2][kCvD], ec[2][kCvD], tc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      tc[k] = sT[ty0 + 4 * k + HALF][tx + HALF];
+#pragma unroll
+      for (int q = 0; q < kCvD; ++q) {
+        acc[k][q] = 0.f;
+        ec[k][q] = sP[ty0 + 4 * k + HALF][cx[HALF] - (db + q)];    // centre of P_d: P[y][clamp(x - d)]
+      }
+    }
+#pragma unroll 1
+    for (int dy = 0; dy < BS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < BS; ++dx)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int ty = ty0 + 4 * k;
+          const float t = sT[ty + dy][tx + dx];
+          float tb = 0.f;
+          if (TYPE >= 2) {
+            const float dta = t - tc[k];
+            tb = dta * __builtin_amdgcn_rsqf(fmaf(dta, dta, eps));
+          }
+          const float* row = &sP[ty + dy][cx[dx] - db];
+#pragma unroll
+          for (int q = 0; q < kCvD; ++q) {
+            const float e = row[-q];
+            if (TYPE == 0) {
+              const float df = e - t;
+              acc[k][q] = fmaf(df, df, acc[k][q]);
+            } else if (TYPE == 1) {
+              acc[k][q] += fabsf(e - t);
+            } else {
+              const float des = e - ec[k][q];
+              const float d2 = des * __builtin_amdgcn_rsqf(fmaf(des, des, eps)) - tb;   // 2 * (h(des) - h(dta))
+              if (TYPE == 2) acc[k][q] = fmaf(d2, d2, acc[k][q]);
+              else acc[k][q] += fabsf(d2);
+            }
+          }
+        }
+    const float scale = (TYPE == 2 ? 0.25f : (TYPE == 3 ? 0.5f : 1.f)) / (float)(BS * BS);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int y = y0 + ty0 + 4 * k;
+      if (x < W && y < H) {
+#pragma unroll
+        for (int q = 0; q < kCvD; ++q) {
+          const int d = d0 + db + q;
+          if (d < D) cost[((long)f * D + d) * HW + (long)y * W + x] = acc[k][q] * scale;
+        }
+      }
+    }
+  }
+}
+
+template <int BS>
+static int costvol_fast_type(int type, const float* im, const float* pat, long pat_frame_stride, float* cost, int frames,
+                             int H, int W, int D, float eps, hipStream_t stream) {
+  const int n_chunks = ceil_div(D, kCvChunk);
+  const dim3 grid(ceil_div(W, kPTW), ceil_div(H, kPTH), frames * n_chunks);
+  switch (type) {
+    case 0: hipLaunchKernelGGL((costvol_fast_kernel<0, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps); break;
+    case 1: hipLaunchKernelGGL((costvol_fast_kernel<1, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps); break;
+    case 2: hipLaunchKernelGGL((costvol_fast_kernel<2, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps); break;
+    case 3: hipLaunchKernelGGL((costvol_fast_kernel<3, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps); break;
+    default: return CTD_ERR_INVALID_ARG;
+  }
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W,
+                     int D, int bs, int type, float eps, hipStream_t stream) {
+  if ((long)frames * ceil_div(D, kCvChunk) > 65535) return CTD_ERR_INVALID_ARG;
+  switch (bs) {
+    case 3: return costvol_fast_type<3>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+    case 5: return costvol_fast_type<5>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+    case 7: return costvol_fast_type<7>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+    case 9: return costvol_fast_type<9>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+    default: return CTD_ERR_UNSUPPORTED;
+  }
+}
+
 int photometric_fwd_fast_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,
                              float eps, hipStream_t s) {
   return dispatch_fast(false, es, ta, nullptr, out, B, C, H, W, bs, type, eps, s);

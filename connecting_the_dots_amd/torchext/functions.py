@@ -508,7 +508,7 @@ def photometric_loss_pytorch(es, ta, block_size, type='mse', eps=0.1):
     return term.reshape(B, -1, H, W).sum(dim=1, keepdim=True) / block_size ** 2
 
 
-def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1):
+def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1, algo=None):
     """Additive: SAD / MSE / soft-census block cost volume between frames and the pattern shifted by d
     (SURVEY 8a/A6): cost[f,d] = photometric_loss(P_d, im[f]) with P_d[h,x] = P[h, clamp(x-d)].
     im [N,H,W] | [H,W] f32, pattern [H,W] | [N,H,W] -> [N,D,H,W] | [D,H,W]; argmin over d is the best match."""
@@ -526,7 +526,8 @@ def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1):
     stride = 0 if pattern.dim() == 2 else H * W
     D = int(n_disps)
     out = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
-    st = _lib.lib().ctd_costvol_f32(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
+    fn = _lib.lib().ctd_costvol_fast_f32 if _photo_fast(a, block_size, algo) else _lib.lib().ctd_costvol_f32
+    st = fn(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
                                     _PHOTO_TYPES[type], float(eps), dev.index, _stream(dev))
     _lib.check(st, "costvol")
     return out[0] if squeeze else out

@@ -150,6 +150,10 @@ int ctd_photometric_bwd_f64(const double* es, const double* ta, const double* gr
 int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
                     int frames, int H, int W, int D, int block_size, int type, float eps,
                     int device, void* stream);
+/* tolerance-level variant (odd block sizes 3/5/7/9): |fast - exact| <= 1e-5 |exact| + 1e-6 */
+int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
+                    int frames, int H, int W, int D, int block_size, int type, float eps,
+                    int device, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * Local contrast normalisation, fused.  Replaces the op chain of LCN.tforward,

@@ -191,3 +191,20 @@ def test_fast_full_size_properties(te):
         bad = (a.grad - b.grad).abs() > 1e-5 * b.grad.abs() + 1e-6
         assert int(bad.sum()) == 0, "%s: %d of %d gradient entries out of tolerance, max %.3g" % (
             ty, int(bad.sum()), bad.numel(), float((a.grad - b.grad).abs().max()))
+
+
+@pytest.mark.parametrize("ty", TYPES)
+@pytest.mark.parametrize("shape", [(24, 150, 40, 9), (37, 64, 7, 5), (9, 70, 33, 9), (16, 200, 70, 3)])
+def test_costvol_fast_vs_oracle(te, oracle, ty, shape):
+    """A6, algo='fast': image borders (both clamps), disparities beyond one LDS chunk (32), D not a multiple of 8"""
+    H, W, D, bs = shape
+    rs = np.random.RandomState(sum(shape))
+    im = rs.randn(H, W).astype(np.float32)
+    pat = rs.randn(H, W).astype(np.float32)
+    ref = oracle.costvol(im, pat, D, bs, TYPES.index(ty), 0.5, nthreads=4)
+    got = te.costvol(dev(im), dev(pat), D, bs, ty, 0.5, algo="fast").cpu().numpy()
+    assert_close(got, ref, what="costvol %s %s" % (ty, (shape,)))
+    # batched frames with per-frame patterns
+    ims, pats = np.stack([im, pat]), np.stack([pat, im])
+    gb = te.costvol(dev(ims), dev(pats), D, bs, ty, 0.5, algo="fast").cpu().numpy()
+    assert_close(gb[0], ref, what="batched")
