@@ -14,9 +14,6 @@
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
 
-#ifndef CTD_RESOLVE_ABLATE
-#define CTD_RESOLVE_ABLATE 0   // timing experiments only
-#endif
 
 namespace ctd {
 
@@ -214,17 +211,12 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
   int64_t* hard_list = (int64_t*)((char*)workspace + 16);
   CTD_HIP_TRY(hipMemsetAsync(n_hard, 0, 16, stream));
   const bool vec4 = W % 4 == 0 && ((uintptr_t)vol % 16) == 0;
-  static const int px_env = getenv("CTD_SCAN_PX") ? atoi(getenv("CTD_SCAN_PX")) : 4;
-  static const int lds_env = getenv("CTD_SCAN_LDS") ? atoi(getenv("CTD_SCAN_LDS")) : 0;
-  const int px = vec4 ? px_env : 1;
+  const int px = vec4 ? 4 : 1;
   if (px == 4)
-    hipLaunchKernelGGL(argmax_scan_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), lds_env, stream, vol,
+    hipLaunchKernelGGL(argmax_scan_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, vol,
                        idx, best, D, HW, W, bs, eps, total / 4, n_hard, hard_list);
-  else if (px == 2)
-    hipLaunchKernelGGL(argmax_scan_kernel<2>, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), lds_env, stream, vol,
-                       idx, best, D, HW, W, bs, eps, total / 2, n_hard, hard_list);
   else
-    hipLaunchKernelGGL(argmax_scan_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), lds_env, stream, vol, idx,
+    hipLaunchKernelGGL(argmax_scan_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, vol, idx,
                        best, D, HW, W, bs, eps, total, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   if (eps < 0.f) return CTD_OK;                            // nothing is marked: plain argmax of the fast volume

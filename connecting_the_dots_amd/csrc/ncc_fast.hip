@@ -35,9 +35,6 @@
 #ifndef CTD_FIXUP_BLOCKS
 #define CTD_FIXUP_BLOCKS 2048
 #endif
-#ifndef CTD_FIX_ABLATE
-#define CTD_FIX_ABLATE 0   // timing experiments only
-#endif
 #ifndef CTD_ABLATE2
 #define CTD_ABLATE2 0   // bit 0: no DPP combine, bit 1: no finalize, bit 2: no pattern-side LDS reads, bit 3: no vertical tree
 #endif
@@ -254,9 +251,6 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
           bad = bad | (cond_factor(m0[oa], v0[oa], n) * cond_factor(m1[ob], v1[ob], n) > kPairLimit);
         }
       }
-#if CTD_FIX_ABLATE == 3
-      bad = false;
-#endif
       float val = 0.f;
       if (__any(bad)) {
         for (int c = 0; c < C; ++c) {
@@ -310,7 +304,7 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
                 for (int bw = 0; bw < bs; ++bw) s_f += sFv[bh * bs + bw] * sFv[bh * bs + bw];
             }
           }
-          if (bad && CTD_FIX_ABLATE != 2) {
+          if (bad) {
             const int off = is_a ? (D - 1) - d : d;
             float mu_s = 0.f, s_s = 0.f, dot = 0.f;
             for (int bh = 0; bh < bs; ++bh) {

@@ -49,3 +49,16 @@ def one_launch():
 B = Bm; H, W = 480, 640
 timeit("4-level pattern loss, per level", per_level)
 timeit("4-level pattern loss, one launch", one_launch)
+# A10: two-view geometric loss (both directions), 15 consecutive pairs of 432x512 depth maps
+import numpy as np
+B = 15; H, W = 432, 512
+K = torch.tensor([[567.6, 0, 324.7], [0, 570.2, 250.1], [0, 0, 1]], device="cuda"); Ki = torch.linalg.inv(K.double()).float()
+depth = (0.5 + torch.rand(16, 1, H, W, device="cuda") * 3).requires_grad_(True)
+R = torch.eye(3, device="cuda").repeat(16, 1, 1).contiguous(); t = (torch.randn(16, 3, device="cuda") * 0.02).contiguous()
+gl = te.ProjectionDepthSimilarityLoss(K, Ki, H, W, clamp=0.1)
+def geo_fwd():
+    with torch.no_grad(): gl(depth[:-1].contiguous(), depth[1:].contiguous(), R[:-1].contiguous(), t[:-1].contiguous(), R[1:].contiguous(), t[1:].contiguous())
+def geo_fb():
+    v = gl(depth[:-1].contiguous(), depth[1:].contiguous(), R[:-1].contiguous(), t[:-1].contiguous(), R[1:].contiguous(), t[1:].contiguous()); v.backward(); depth.grad = None
+timeit("geometric loss fwd (2 directions)", geo_fwd)
+timeit("geometric loss fwd+bwd", geo_fb)
