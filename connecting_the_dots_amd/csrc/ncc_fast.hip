@@ -987,9 +987,12 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 // (tools/ubench_struct.hip), hence 16 disparities per workgroup.
 // ------------------------------------------------------------------------------------
 #ifndef CTD_TWAVES
-#define CTD_TWAVES 6
+#define CTD_TWAVES 7
 #endif
-constexpr int kTWaves = CTD_TWAVES;            // consumer wavefronts per workgroup (6: two 7-wave workgroups per CU at 128 VGPRs)
+constexpr int kTWaves = CTD_TWAVES;            // consumer wavefronts per workgroup.  7 (+ loader) = two 8-wave workgroups per CU at
+                                               // 128 VGPRs = exactly 4 waves on every SIMD; with 6 two SIMDs carry 4 waves and two
+                                               // carry 3, and the chunk barrier makes the lighter ones wait (measured: 7 is 9 % faster
+                                               // although 10 groups of 14 disparities compute 140 for D = 128)
 constexpr int kTND = 2;                        // disparities per lane
 constexpr int kTDG = kTWaves * kTND;           // 16 disparities per workgroup
 constexpr int kTTile = 256;                    // output columns per workgroup
@@ -1041,6 +1044,11 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
   auto quad = [](const float* p) { return *(const f32x4*)p; };
 
   wg_barrier();                                                    // chunk 0 (operands + halos) is in LDS
+  if (d_base >= D) {
+    // both disparities of this wavefront lie past D (last disparity group): keep the barrier protocol, skip the work
+    for (int it = 0; it < n_iters * (STEP / kTRows); ++it) wg_barrier();
+    return;
+  }
   int chunk = 0;
   for (int it = 0; it < n_iters; ++it) {
 #pragma unroll
@@ -1148,6 +1156,8 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
   const int n_chunks = n_iters * CPI;
 
   if (wave == kTWaves) {
+    // every chunk barrier waits for this wavefront's DMA issue and halo sums: it goes first on its SIMD (-4 %)
+    __builtin_amdgcn_s_setprio(3);
     // ------------------------------ loader + halo wavefront ------------------------------
     const float* a_img = ac + ((long)f * C + c) * H * Wp + 4;      // +4: column c lives at c + 4
     const float* m0i = m0 + ((long)f * C + c) * H * Wp + 4;
@@ -1354,7 +1364,10 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     // production path: 256-column tiles, every store a full aligned KB
     const int n_dg = ceil_div(D, kTDG);
     const int n_tiles = ceil_div(W, kTTile);
-    const int bands = pick_bands((long)n_tiles * frames * n_dg, H, BS);
+    // Bands of ~44 rows (5.5x the (bs-1)-row warm-up).  Measured on config 2 (H = 432): 4 bands 0.448 ms, 8: 0.418,
+    // 10: 0.394, 12: 0.398, 16: 0.439 -- short bands cost warm-up rows but interleave the store-free warm-up of
+    // some workgroups with the store phase of others and even out the tail.
+    const int bands = H >= 66 ? (H + 22) / 44 : 1;
     const int band_rows = ceil_div(H, bands);
     dim3 grid(n_tiles, ceil_div(H, band_rows), frames * n_dg), block(64 * (kTWaves + 1));
     const size_t lds = sizeof(float) * kTBufs * kTRows * kTPack;
