@@ -1056,76 +1056,74 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
       const float* pk = lds + ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack;
-      // The nine 16-byte operand reads of the row are requested together; only the first pin below (frame and
-      // pattern values) must be satisfied before the products start, the pins of the statistics quads carry a
-      // data dependency on the window sums, so the compiler is free to leave part of the reads in flight
-      // under the vertical / horizontal sums (it currently waits for six and sinks three past the products).
+      // Phase A, every row: products and the vertical 3+3+3 rings of both disparities (needs only the two value
+      // quads).  Phase B, output rows only (wave-uniform branch; the (bs-1) warm-up rows of a band skip it):
+      // statistics quads requested first so that they arrive under the horizontal sums, then window sums,
+      // normalisation and the store.
       const float* own = pk + 4 * (lane + 1);                      // own quad after the left halo
       f32x4 qa = quad(own);
       f32x4 qb0 = quad(pk + kTOffB + 4 * (lane + 1 + kQ)), qb1 = quad(pk + kTOffB + 4 * (lane + 2 + kQ));
-      f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
-      f32x4 qm0 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 1 + kQ)), qm1 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 2 + kQ));
-      f32x4 qs0 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 1 + kQ)), qs1 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 2 + kQ));
-      asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));                    // first wait: products may start
+      asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
       const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
       const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
       const int h = r - TAIL;
       const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
-      float me[8], se[8];
+      float x[kTND][4];
 #pragma unroll
-      for (int j = 0; j < kTND; ++j) {
-        float x[4];
+      for (int j = 0; j < kTND; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float p = av[i] * be[kS + (1 - j) + i];            // b[j][i] = slot kOff0 - j + i
           const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
           P[j][i][u % 2] = p;
-          x[i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+          x[j][i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
           T[j][i][u % 6] = t3;
         }
-        float pre[4], suf[4];
-        pre[0] = x[0];
-        pre[1] = pre[0] + x[1];
-        pre[2] = pre[1] + x[2];
-        pre[3] = pre[2] + x[3];
-        suf[3] = x[3];
-        suf[2] = suf[3] + x[2];
-        suf[1] = suf[2] + x[1];
-        suf[0] = suf[1] + x[0];
-        float sj[4];
-        window_combine4(suf, pre[3], pre, sj);                      // wave-edge lanes get 0 from the missing neighbour
-        if (j == 0) {
-          // second wait: statistics and halo quads (the dependency on the sums keeps it after them)
-          asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
-          asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
+      if (row_out) {
+        f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
+        f32x4 qm0 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 1 + kQ)), qm1 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 2 + kQ));
+        f32x4 qs0 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 1 + kQ)), qs1 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 2 + kQ));
+        float me[8], se[8];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
-        }
-        // halo quad of this disparity: issued before the sums of the row's second disparity, so only the
-        // first one of a row is waited for at full latency
-        f32x4 hq = quad(pk + kTOffH + ((WAVE * kTND + j) * 2 + halo_side) * 4);
-        asm("" : "+v"(hq));
-        float val[4];
+        for (int j = 0; j < kTND; ++j) {
+          float pre[4], suf[4];
+          pre[0] = x[j][0];
+          pre[1] = pre[0] + x[j][1];
+          pre[2] = pre[1] + x[j][2];
+          pre[3] = pre[2] + x[j][3];
+          suf[3] = x[j][3];
+          suf[2] = suf[3] + x[j][2];
+          suf[1] = suf[2] + x[j][1];
+          suf[0] = suf[1] + x[j][0];
+          float sj[4];
+          window_combine4(suf, pre[3], pre, sj);                    // wave-edge lanes get 0 from the missing neighbour
+          if (j == 0) {
+            // statistics quads: pinned after the first window sums (data dependency keeps the wait here)
+            asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
+            asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float sh = fmaf(halo_mask, hq[i], sj[i]);
-          const float cov = fmaf(-nf * qma[i], me[kS + (1 - j) + i], sh);
-          const float den = fmaf(qsa[i], se[kS + (1 - j) + i], 1e-8f);
-          val[i] = cov * __builtin_amdgcn_rcpf(den);
-        }
-        const int d = d_base + j;
-#if CTD_ABLATE == 1
-        if (row_out && lane_out && d < D && val[0] == 123456.789f) {
-#else
-        if (row_out && lane_out && d < D) {
-#endif
-          float4* o = (float4*)(vol + (long)d * HW + (long)h * W + c0);
-          float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
-          if (ACCUM) {
-            const float4 old = *o;
-            v4.x += old.x; v4.y += old.y; v4.z += old.z; v4.w += old.w;
+            for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
           }
-          *o = v4;
+          f32x4 hq = quad(pk + kTOffH + ((WAVE * kTND + j) * 2 + halo_side) * 4);
+          asm("" : "+v"(hq));
+          float val[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float sh = fmaf(halo_mask, hq[i], sj[i]);
+            const float cov = fmaf(-nf * qma[i], me[kS + (1 - j) + i], sh);
+            const float den = fmaf(qsa[i], se[kS + (1 - j) + i], 1e-8f);
+            val[i] = cov * __builtin_amdgcn_rcpf(den);
+          }
+          const int d = d_base + j;
+          if (lane_out && d < D) {
+            float4* o = (float4*)(vol + (long)d * HW + (long)h * W + c0);
+            float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
+            if (ACCUM) {
+              const float4 old = *o;
+              v4.x += old.x; v4.y += old.y; v4.z += old.z; v4.w += old.w;
+            }
+            *o = v4;
+          }
         }
       }
       if (last_of_chunk) {
