@@ -200,7 +200,7 @@ constexpr long kResolveBlocks = CTD_RESOLVE_BLOCKS;
 
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+                      size_t workspace_bytes, bool counter_cleared, hipStream_t stream) {
   if (D > kMaskWords * 64) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
   const long HW = (long)H * W;
@@ -209,7 +209,7 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
   if (!workspace || workspace_bytes < 16 + sizeof(int64_t) * (size_t)total) return CTD_ERR_WORKSPACE;
   unsigned* n_hard = (unsigned*)workspace;
   int64_t* hard_list = (int64_t*)((char*)workspace + 16);
-  CTD_HIP_TRY(hipMemsetAsync(n_hard, 0, 16, stream));
+  if (!counter_cleared) CTD_HIP_TRY(hipMemsetAsync(n_hard, 0, 16, stream));   // ncc_fixup_runs_kernel clears it
   const bool vec4 = W % 4 == 0 && ((uintptr_t)vol % 16) == 0;
   const int px = vec4 ? 4 : 1;
   if (px == 4)

@@ -139,7 +139,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
                           workspace_bytes, (hipStream_t)stream);
     if (st) return st;
     return argmax_rerank_f32(vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
-                             workspace, workspace_bytes, (hipStream_t)stream);
+                             workspace, workspace_bytes, /*counter_cleared=*/true, (hipStream_t)stream);
   }
   return CTD_ERR_INVALID_ARG;
 }

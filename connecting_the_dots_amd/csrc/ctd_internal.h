@@ -28,7 +28,7 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
 // argmax_rerank.hip
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream);
+                      size_t workspace_bytes, bool counter_cleared, hipStream_t stream);
 
 // photometric.hip
 int photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,

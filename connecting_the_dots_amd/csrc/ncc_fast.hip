@@ -64,18 +64,37 @@ constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - c
 // out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
 // cval = f64 window mean at the image centre, recomputed identically by every workgroup.
+// One launch serves the frames (job a) and the pattern (job b): blockIdx.z < a.nimg -> image blockIdx.z of job a,
+// else image blockIdx.z - a.nimg of job b; workgroups past a job's plane width exit at once.
+struct PrepassJob {
+  const float* in;
+  long frame_stride;
+  float *out_img, *out_mean, *out_dev;
+  int x_start, W_out, nimg;
+  unsigned* n_flag;
+  unsigned long long* flag_list;
+  int col_lo, col_hi;
+  unsigned* n_runs;
+  unsigned long long* run_rows;
+};
+
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
 template <int BSC>
-__global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* __restrict__ in, long frame_stride,
-                                                                  float* __restrict__ out_img,
-                                                                  float* __restrict__ out_mean,
-                                                                  float* __restrict__ out_dev, int H, int W,
-                                                                  int x_start, int W_out, int bs_rt,
-                                                                  unsigned* __restrict__ n_flag,
-                                                                  unsigned long long* __restrict__ flag_list,
-                                                                  int col_lo, int col_hi,
-                                                                  unsigned* __restrict__ n_runs,
-                                                                  unsigned long long* __restrict__ run_rows) {
+__global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja, PrepassJob jb, int H, int W, int bs_rt) {
+  const bool is_a = (int)blockIdx.z < ja.nimg;
+  const PrepassJob& jp = is_a ? ja : jb;
+  const int img_idx = is_a ? (int)blockIdx.z : (int)blockIdx.z - ja.nimg;
+  const float* __restrict__ in = jp.in;
+  const long frame_stride = jp.frame_stride;
+  float* __restrict__ out_img = jp.out_img;
+  float* __restrict__ out_mean = jp.out_mean;
+  float* __restrict__ out_dev = jp.out_dev;
+  const int x_start = jp.x_start, W_out = jp.W_out, col_lo = jp.col_lo, col_hi = jp.col_hi;
+  unsigned* __restrict__ n_flag = jp.n_flag;
+  unsigned long long* __restrict__ flag_list = jp.flag_list;
+  unsigned* __restrict__ n_runs = jp.n_runs;
+  unsigned long long* __restrict__ run_rows = jp.run_rows;
+  if ((int)blockIdx.x * kSTW >= W_out) return;
   extern __shared__ double lds_d[];
   __shared__ double cred[kSTW * kSRows];
   const int bs = BSC > 0 ? BSC : bs_rt;
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
   float* tile = (float*)(lds_d + 2 * TRr * kSTW);
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kSTW + tx;
   const int xi_lo = blockIdx.x * kSTW, h_lo = blockIdx.y * kSTH;
-  const float* img = in + (long)blockIdx.z * frame_stride;      // z = frame * C + channel
+  const float* img = in + (long)img_idx * frame_stride;          // image = frame * C + channel
   {
     double t = 0;
     for (int k = tid; k < bs * bs; k += kSTW * kSRows) {
@@ -154,15 +173,15 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(const float* 
     const bool flat = 4e-8 * n * mean * mean > var;
     const bool listed = flat || n * mc * mc > kFlagRatio * var;
     const float dev = (float)sqrt(var > 0 ? var : 0.0);
-    const long o = ((long)blockIdx.z * H + h) * W_out + xi;
+    const long o = ((long)img_idx * H + h) * W_out + xi;
     out_mean[o] = (float)mc;
     out_dev[o] = flat ? -dev : dev;
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     const int col = xi + x_start;
     if (listed && col >= col_lo && col < col_hi) {
-      flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)blockIdx.z << 40) | ((unsigned long long)h << 20) |
+      flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)img_idx << 40) | ((unsigned long long)h << 20) |
                                          (unsigned long long)(col + 0x80000);
-      if (run_rows && col == col_lo) run_rows[atomicAdd(n_runs, 1u)] = ((unsigned long long)blockIdx.z << 20) | (unsigned long long)h;
+      if (run_rows && col == col_lo) run_rows[atomicAdd(n_runs, 1u)] = ((unsigned long long)img_idx << 20) | (unsigned long long)h;
     }
   }
 }
@@ -350,13 +369,17 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__ out, const float* __restrict__ run_vals,
                                                              const unsigned* __restrict__ counters,
                                                              const unsigned long long* __restrict__ run_rows, int per_frame,
-                                                             int frames, int C, int H, int W, int D, int bs) {
+                                                             int frames, int C, int H, int W, int D, int bs,
+                                                             unsigned* __restrict__ rank_counter) {
   extern __shared__ int s_rows[];                          // up to C * H rows of this frame's pattern
   __shared__ int s_n;
   const int tid = threadIdx.x;
   const int f = blockIdx.x / D, d = blockIdx.x - f * D;
   const int tail = bs - 1 - bs / 2;
   const int seg = min(d - tail + 1, W);                    // pixels w in [0, d - tail]
+  // the work-list counter of the ranking pass that may follow (argmax_rerank.hip) lives at the start of the
+  // workspace, which the volume kernel is done with by now: cleared here instead of by a memset of its own
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *rank_counter = 0u;
   const unsigned n_r = counters[2];
   if (seg <= 0 || n_r == 0) return;
   if (tid == 0) s_n = 0;
@@ -1332,15 +1355,13 @@ size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, 
   return fast_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
 }
 
-static int launch_prepass(const float* in, long frame_stride, int nimg, float* cimg, float* mean, float* dev, int H,
-                          int W, int x_start, int W_out, int bs, unsigned* n_flag, unsigned long long* flag_list,
-                          int col_lo, int col_hi, unsigned* n_runs, unsigned long long* run_rows, hipStream_t stream) {
+static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int W, int bs, hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
-  dim3 grid(ceil_div(W_out, kSTW), ceil_div(H, kSTH), nimg), block(kSTW, kSRows);
-  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, in, frame_stride, cimg, mean, dev, H, W, x_start, W_out,
-                     bs, n_flag, flag_list, col_lo, col_hi, n_runs, run_rows);
+  const int w_out = ja.W_out > jb.W_out ? ja.W_out : jb.W_out;
+  dim3 grid(ceil_div(w_out, kSTW), ceil_div(H, kSTH), ja.nimg + jb.nimg), block(kSTW, kSRows);
+  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, ja, jb, H, W, bs);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -1431,19 +1452,14 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
-  int st = launch_prepass(in0, (long)H * W, frames * C, ws.ac, ws.m0, ws.v0, H, W, -4, ws.Wp, bs, ws.counters,
-                          ws.flag_a, 0, W, nullptr, nullptr, stream);
-  if (st) return st;
-  // pattern statistics per unclamped centre column x = w - d; windows x <= -(bs-1-bs/2) are all the same
-  // fully clamped window and are listed once
-  if (per_frame) {
-    if (in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
-    st = launch_prepass(in1, (long)H * W, frames * C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, ws.counters + 1,
-                        ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, stream);
-  } else {
-    st = launch_prepass(in1, (long)H * W, C, ws.bc, ws.m1, ws.v1, H, W, -ws.xoff, ws.W1, bs, ws.counters + 1, ws.flag_b,
-                        -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, stream);
-  }
+  // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
+  // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
+  if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
+  const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
+                         nullptr, nullptr};
+  const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows};
+  int st = launch_prepass(ja, jb, H, W, bs, stream);
   if (st) return st;
   switch (bs) {
     case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
@@ -1467,7 +1483,7 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   const size_t lds_rows = sizeof(int) * (size_t)C * H;
   if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
-                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs);
+                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, (unsigned*)workspace);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
