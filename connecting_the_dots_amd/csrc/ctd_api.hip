@@ -377,4 +377,19 @@ int ctd_proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, int
   return proj_nn_f64(xyz0, xyz1, K, B, H, W, patch_size, out, (hipStream_t)stream);
 }
 
+int ctd_render_mesh_proj_f32(const float* verts, const float* colors, int n_verts, const int* faces, int n_faces,
+                             const float* cam, int cam_width, int cam_height, const float* proj, int proj_width,
+                             int proj_height, const float* shader, const float* pattern, float d_alpha, float d_beta,
+                             float* depth, float* color, float* normal, int device, void* stream) {
+  if (n_verts < 0 || n_faces < 0 || cam_width <= 0 || cam_height <= 0 || proj_width <= 0 || proj_height <= 0 ||
+      (double)cam_width * cam_height * 3 >= 2147483648.0)
+    return CTD_ERR_INVALID_ARG;
+  if (!cam || !proj || !shader || !pattern || !color || (n_faces > 0 && (!verts || !colors || !faces)))
+    return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return render_mesh_proj_f32(verts, colors, faces, n_faces, cam, cam_width, cam_height, proj, proj_width, proj_height,
+                              shader, pattern, d_alpha, d_beta, depth, color, normal, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -93,4 +93,10 @@ int proj_nn_f32(const float* xyz0, const float* xyz1, const float* K, long B, lo
 int proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, long B, long H, long W, int patch_size,
                 int64_t* out, hipStream_t s);
 
+// render.hip
+int render_mesh_proj_f32(const float* verts, const float* colors, const int* faces, int n_faces, const float* cam_p,
+                         int cam_w, int cam_h, const float* proj_p, int proj_w, int proj_h, const float* shader,
+                         const float* pattern, float d_alpha, float d_beta, float* depth, float* color, float* normal,
+                         hipStream_t stream);
+
 }  // namespace ctd

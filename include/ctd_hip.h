@@ -275,6 +275,25 @@ int ctd_proj_nn_f32(const float* xyz0, const float* xyz1, const float* K, int B,
 int ctd_proj_nn_f64(const double* xyz0, const double* xyz1, const double* K, int B, int H, int W,
                     int patch_size, int64_t* out, int device, void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * Synthetic structured-light rendering (data side of the path).
+ * Replaces RendererGpu<float>::render_mesh_proj -- renderer/render/render_gpu.h,
+ * functor RenderProjectorFunctor renderer/render/render.h:251-364 (Python: PyRenderer.mesh_proj,
+ * renderer/cyrender.pyx:196-199): brute-force ray casting of a triangle mesh from the camera,
+ * shadow ray from the projector, bilinear fetch of the projected pattern with distance decay
+ * max(1, (d_alpha + d_beta * d)^2), Phong-shaded vertex colours as the ambient image.
+ *   verts, colors [n_verts][3] f32, faces [n_faces][3] int32, pattern [proj_height][proj_width][3]: device
+ *   cam, proj = { fx, fy, px, py, R[9] row-major, t[3] } (16 floats), shader = { ka, kd, ks, alpha }: HOST
+ *   depth [H][W] (-1 where nothing is hit; may be NULL), color [H][W][3], normal [H][W][3] (may be NULL;
+ *   left untouched where nothing is hit, as in the reference): device
+ * depth / color are bit-identical to the reference CPU build; normal too when ks == 0.
+ * -------------------------------------------------------------------------------------- */
+int ctd_render_mesh_proj_f32(const float* verts, const float* colors, int n_verts, const int* faces,
+                             int n_faces, const float* cam, int cam_width, int cam_height,
+                             const float* proj, int proj_width, int proj_height, const float* shader,
+                             const float* pattern, float d_alpha, float d_beta, float* depth,
+                             float* color, float* normal, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

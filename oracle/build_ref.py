@@ -55,6 +55,36 @@ def build(force=False, verbose=True):
     return so
 
 
+RENDER_DIR = "/root/reference/renderer/render"
+RENDER_OUT = os.path.join(OUT_DIR, "ctd_ref_render.so")
+RENDER_DRIVER = os.path.join(HERE, "ref_render_driver.cpp")
+
+
+def build_render(verbose=True):
+    """The reference's CPU renderer (renderer/render/*.h, render_cpu.cpp) behind oracle/ref_render_driver.cpp,
+    compiled with the reference's own flags (renderer/setup.py: -O3 -std=c++11; no FMA on baseline x86-64).
+    Returns the path, or None where the reference is absent."""
+    if not os.path.exists(os.path.join(RENDER_DIR, "render_cpu.cpp")):
+        return RENDER_OUT if os.path.exists(RENDER_OUT) else None
+    if os.path.exists(RENDER_OUT) and os.path.getmtime(RENDER_OUT) >= os.path.getmtime(RENDER_DRIVER):
+        return RENDER_OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O3", "-std=c++11", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-w", "-I", RENDER_DIR,
+           RENDER_DRIVER, "-o", RENDER_OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return RENDER_OUT
+
+
+def load_render():
+    import ctypes
+    path = build_render(verbose=False)
+    if path is None:
+        raise RuntimeError("reference renderer not available (no /root/reference and no prebuilt oracle/_ref)")
+    return ctypes.CDLL(path)
+
+
 def load():
     """Import the compiled reference module (needs torch imported first)."""
     import importlib.util

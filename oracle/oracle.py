@@ -173,3 +173,38 @@ def proj_nn(xyz0, xyz1, K, patch_size):
     fn.argtypes = [_vp, _vp, _vp, _c_long, _c_long, _c_long, _c_long, _vp]
     assert fn(_p(xyz0), _p(xyz1), _p(K), B, H, W, patch_size, _p(out)) == 0
     return out
+
+
+def _cam_params(K, R, t):
+    """{fx, fy, px, py, R[9], t[3]} as the reference's Camera<T> constructor takes them (render.h:24)"""
+    return np.ascontiguousarray(np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.asarray(R).reshape(9),
+                                                np.asarray(t).reshape(3)]).astype(np.float32))
+
+
+def render_mesh_proj(verts, colors, faces, cam, proj, shader, pattern, d_alpha, d_beta, nthreads=1, fn=None):
+    """RenderProjectorFunctor (renderer/render/render.h:251-364).  cam / proj = (K [3,3], R [3,3], t [3], width,
+    height); shader = (ka, kd, ks, alpha); pattern [ph, pw, 3] -> depth [H,W], color [H,W,3], normal [H,W,3]
+    (normal zero-initialised here; the reference leaves it untouched where nothing is hit)."""
+    verts, colors = _c(verts, np.float32), _c(colors, np.float32)
+    faces = _c(faces, np.int32)
+    pattern = _c(pattern, np.float32)
+    cp, pp = _cam_params(*cam[:3]), _cam_params(*proj[:3])
+    W, H = int(cam[3]), int(cam[4])
+    assert pattern.shape == (int(proj[4]), int(proj[3]), 3)
+    depth = np.zeros((H, W), np.float32)
+    color = np.zeros((H, W, 3), np.float32)
+    normal = np.zeros((H, W, 3), np.float32)
+    sh = np.asarray(shader, np.float32)
+    if fn is None:
+        fn = lib().ctd_oracle_render_mesh_proj_f32
+        fn.argtypes = [_vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_float,
+                       _c_float, _vp, _vp, _vp, _c_int]
+        rc = fn(_p(verts), _p(colors), verts.shape[0], _p(faces), faces.shape[0], _p(cp), W, H, _p(pp), int(proj[3]),
+                int(proj[4]), _p(sh), _p(pattern), d_alpha, d_beta, _p(depth), _p(color), _p(normal), nthreads)
+    else:                                   # the reference harness (oracle/ref_render_driver.cpp) takes normals too
+        fn.argtypes = [_vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_float,
+                       _c_float, _vp, _vp, _vp, _c_int]
+        rc = fn(_p(verts), _p(colors), None, verts.shape[0], _p(faces), faces.shape[0], _p(cp), W, H, _p(pp),
+                int(proj[3]), int(proj[4]), _p(sh), _p(pattern), d_alpha, d_beta, _p(depth), _p(color), _p(normal), nthreads)
+    assert rc == 0
+    return depth, color, normal

@@ -318,10 +318,25 @@ def gen_nn_ops(ext):
     save("nn_ops", **out)
 
 
+def gen_render():
+    """RendererCpu<float>::render_mesh_proj of the reference (renderer/render/render_cpu.cpp:17-20) through
+    oracle/ref_render_driver.cpp: depth / projected pattern / shaded ambient image of three small scenes"""
+    from oracle import oracle as ora
+    ref = build_ref.load_render().ctd_ref_render_mesh_proj
+    out = {}
+    for k, (seed, wall, shader) in enumerate(((1, True, (0.5, 1.5, 0.0, 10.0)), (2, True, (0.3, 1.0, 0.4, 8.0)),
+                                              (3, False, (0.5, 1.5, 0.0, 10.0)))):
+        sc = workloads.render_scene(seed, wall=wall)
+        sc["shader"] = shader
+        d, c, n = ora.render_mesh_proj(**sc, fn=ref)
+        out["depth_%d" % k], out["color_%d" % k], out["normal_%d" % k] = d, c, n
+    save("render", **out)
+
+
 def main():
     ext = build_ref.load()
     te, nets = ref_python.load()
-    which = sys.argv[1:] or ["xcorr", "photo", "costvol", "lcn", "lcncy", "losses", "patloss", "nnops", "cfg1"]
+    which = sys.argv[1:] or ["xcorr", "photo", "costvol", "lcn", "lcncy", "losses", "patloss", "nnops", "render", "cfg1"]
     if "xcorr" in which:
         gen_xcorrvol(ext)
     if "photo" in which:
@@ -338,6 +353,8 @@ def main():
         gen_pattern_loss(nets)
     if "nnops" in which:
         gen_nn_ops(ext)
+    if "render" in which:
+        gen_render()
     if "cfg1" in which:
         gen_cfg1(ext)
 

@@ -137,3 +137,18 @@ def test_nn_crosscheck_proj_nn_bit_exact(oracle, tag, dt):
     xyz0, xyz1, K = workloads.proj_case(4, dt)
     for ps in (1, 3, 4, 5):
         assert np.array_equal(oracle.proj_nn(xyz0, xyz1, K, ps), g["proj%d_%s" % (ps, tag)]), ps
+
+
+def test_render_mesh_proj_bit_exact(oracle):
+    """renderer/render/render.h:251-364 restated; goldens from the reference's own RendererCpu<float>"""
+    from tests import workloads
+    g = golden("render")
+    for k, (seed, wall, shader) in enumerate(((1, True, (0.5, 1.5, 0.0, 10.0)), (2, True, (0.3, 1.0, 0.4, 8.0)),
+                                              (3, False, (0.5, 1.5, 0.0, 10.0)))):
+        sc = workloads.render_scene(seed, wall=wall)
+        sc["shader"] = shader
+        d, c, n = oracle.render_mesh_proj(**sc, nthreads=4)
+        assert np.array_equal(d, g["depth_%d" % k]) and np.array_equal(c, g["color_%d" % k]), k
+        assert np.array_equal(n, g["normal_%d" % k]), k
+        if not wall:
+            assert (d == -1).any() and (c[d == -1] == 0).all() and (n[d == -1] == 0).all()

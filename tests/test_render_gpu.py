@@ -1,0 +1,77 @@
+"""N4: synthetic structured-light renderer (camera rays, projector shadow rays, pattern inpainting, Phong ambient)
+through the reference-shaped `renderer` API -- bit-exact against the goldens captured from the reference's own
+RendererCpu<float> (tests/golden/render.npz) and against the oracle on a larger mesh."""
+import numpy as np
+import pytest
+import torch
+
+from tests import workloads
+from tests.util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+CASES = ((1, True, (0.5, 1.5, 0.0, 10.0)), (2, True, (0.3, 1.0, 0.4, 8.0)), (3, False, (0.5, 1.5, 0.0, 10.0)))
+
+
+def run(sc):
+    from connecting_the_dots_amd import renderer
+    K, R, t, W, H = sc["cam"]
+    cam = renderer.PyCamera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], R, t, W, H)
+    Kp, Rp, tp, Wp, Hp = sc["proj"]
+    proj = renderer.PyCamera(Kp[0, 0], Kp[1, 1], Kp[0, 2], Kp[1, 2], Rp, tp, Wp, Hp)
+    data = renderer.PyRenderInput(verts=sc["verts"], colors=sc["colors"], faces=sc["faces"])
+    r = renderer.PyRenderer(cam, renderer.PyShader(*sc["shader"]), engine='gpu')
+    r.mesh_proj(data, proj, sc["pattern"], d_alpha=sc["d_alpha"], d_beta=sc["d_beta"])
+    return r.depth(), r.color(), r.normal()
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_golden(k):
+    seed, wall, shader = CASES[k]
+    sc = workloads.render_scene(seed, wall=wall)
+    sc["shader"] = shader
+    g = golden("render")
+    d, c, n = run(sc)
+    assert np.array_equal(d, g["depth_%d" % k]), "depth"
+    assert np.array_equal(c, g["color_%d" % k]), "projected pattern"
+    if shader[2] == 0.0:
+        assert np.array_equal(n, g["normal_%d" % k]), "ambient image"
+    else:                                   # ks != 0: powf differs in its last bits between libm and the device
+        assert_close(n, g["normal_%d" % k], rtol=1e-5, atol=1e-6, what="ambient image")
+
+
+def test_vs_oracle_larger_mesh_and_api_errors(oracle):
+    """more faces than one LDS tile (256), 120 x 160 image"""
+    from connecting_the_dots_amd import renderer
+    sc = workloads.render_scene(9, H=120, W=160, n_boxes=40)
+    assert sc["faces"].shape[0] > 256
+    d, c, n = run(sc)
+    od, oc, on = oracle.render_mesh_proj(**sc, nthreads=8)
+    assert np.array_equal(d, od) and np.array_equal(c, oc) and np.array_equal(n, on)
+    # shadows exist (a box occludes the projector) and lit pixels carry pattern energy
+    lit = c.sum(-1) > 0
+    assert 0.5 < lit.mean() < 1.0 and (d > 0).all()
+    with pytest.raises(Exception):
+        renderer.PyRenderInput(verts=np.zeros((4, 2), np.float32))
+    with pytest.raises(Exception):
+        renderer.PyRenderer(None, None, engine='cpu')
+
+
+def test_disparity_consistency_of_the_rendered_pattern():
+    """fronto-parallel wall at depth z: the pattern must appear shifted by the disparity f * b / z (the relation
+    the data generator relies on, create_syn_data.py:163)"""
+    H, W = 64, 256
+    sc = workloads.render_scene(0, H=H, W=W, n_boxes=0)
+    z = 2.0
+    sc["verts"] = np.array([[-9, -9, z], [9, -9, z], [9, 9, z], [-9, 9, z]], np.float32)
+    sc["colors"] = np.ones((4, 3), np.float32)
+    sc["faces"] = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    sc["d_beta"] = 0.0
+    pat = np.zeros((H, W, 3), np.float32)
+    pat[:, 100] = 1.0                                   # a single bright projector column
+    sc["pattern"] = pat
+    d, c, n = run(sc)
+    f, b = sc["cam"][0][0, 0], 0.075
+    col = int(np.argmax(c[H // 2, :, 0]))
+    assert abs(col - (100 - f * b / z)) <= 1.0          # u_proj = u_cam + f*b/z for x_proj = x_cam + b
+    assert np.allclose(d, z, rtol=1e-6)

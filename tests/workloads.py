@@ -56,3 +56,37 @@ def proj_case(seed, dt, B=2, H=24, W=32):
     xyz0[0, 0, 1] = [1, 1, 0]      # infinite projection
     xyz0[1, 3, 4] = [-50, 0, 1]    # projects far left of the image
     return xyz0, xyz1, K
+
+
+def render_scene(seed, H=48, W=64, n_boxes=4, wall=True):
+    """Small structured-light scene for the renderer tests: a slanted back wall plus a few random boxes in front
+    of it, a pinhole camera at the origin and a projector 7.5 cm to its side (the reference's baseline,
+    data/create_syn_data.py:228-230), a random RGB projector pattern.  Returns the arguments of render_mesh_proj."""
+    rs = np.random.RandomState(seed)
+    verts, faces = [], []
+
+    def quad(p0, p1, p2, p3):
+        b = len(verts)
+        verts.extend([p0, p1, p2, p3])
+        faces.extend([[b, b + 1, b + 2], [b, b + 2, b + 3]])
+
+    if wall:
+        quad([-3, -2, 3.0], [3, -2, 3.5], [3, 2, 3.5], [-3, 2, 3.0])              # back wall (else: rays that miss)
+    for _ in range(n_boxes):
+        c = np.array([rs.uniform(-0.8, 0.8), rs.uniform(-0.5, 0.5), rs.uniform(1.2, 2.4)])
+        s = rs.uniform(0.1, 0.3, size=3)
+        corners = [c + s * np.array([dx, dy, dz]) for dx in (-1, 1) for dy in (-1, 1) for dz in (-1, 1)]
+        for a, b_, c_, d in ((0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)):
+            quad(corners[a], corners[b_], corners[c_], corners[d])
+    verts = np.array(verts, np.float32)
+    faces = np.array(faces, np.int32)
+    colors = rs.uniform(0.3, 1.0, size=verts.shape).astype(np.float32)
+    f = 0.9 * W
+    K = np.array([[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], np.float32)
+    R = np.eye(3, dtype=np.float32)
+    cam = (K, R, np.zeros(3, np.float32), W, H)
+    proj = (K, R, np.array([0.075, 0, 0], np.float32), W, H)          # x_proj = x_cam + baseline
+    pattern = rs.uniform(0, 1, size=(H, W, 3)).astype(np.float32)
+    shader = (0.5, 1.5, 0.0, 10.0)                                    # create_syn_data.py:155
+    return dict(verts=verts, colors=colors, faces=faces, cam=cam, proj=proj, shader=shader, pattern=pattern,
+                d_alpha=0.0, d_beta=0.35)
