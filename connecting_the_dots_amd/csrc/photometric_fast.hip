@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void costvol_fast_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < kCvD; ++q) {
           const int d = d0 + db + q;
-          if (d < D) __builtin_nontemporal_store(acc[k][q] * scale, &cost[((long)f * D + d) * HW + (long)y * W + x]);
+          if (d < D) cost[((long)f * D + d) * HW + (long)y * W + x] = acc[k][q] * scale;
         }
       }
     }
