@@ -209,7 +209,7 @@ def main():
                 "traffic": measured_traffic("ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel"),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[0].cpu())
         print(json.dumps(out), flush=True)
     if dist is not None:
