@@ -104,8 +104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTD_SCAN_WA
 // set with one round of loads (scores within eps of the best; the run of disparities whose window is clamped
 // to column 0 counted once, lowest d); a single candidate is final, otherwise the frame window and the
 // reachable pattern rows are staged in LDS and the wave re-scores each candidate in reference order.
-constexpr int kMaskWords = 8;            // disparities per candidate mask = 512
+constexpr int kMaskWords = 8;            // at most 512 disparities per candidate mask
 
+// WORDS = 64-disparity words of the candidate mask (2 for D <= 128 ... 8 for D <= 512)
+template <int WORDS>
 __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __restrict__ vol,
                                                              const float* __restrict__ in0,
                                                              const float* __restrict__ in1, long in1_frame_stride,
@@ -116,8 +118,13 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
   extern __shared__ float lds_resolve[];
   const int lane = threadIdx.x & 63;
   const int half = bs / 2, span = bs + D - 1;
-  float* sA = lds_resolve + (threadIdx.x >> 6) * (bs * bs + bs * span);   // per-wave staging area
+  // per-wave staging area: frame window / pattern rows, raw and divided by bs^2 (the reference divides every tap
+  // before it sums the means, ext.h:157-158: done once per staged element, not once per candidate and tap)
+  float* sA = lds_resolve + (threadIdx.x >> 6) * 2 * (bs * bs + bs * span);
   float* sB = sA + bs * bs;
+  float* sAq = sB + bs * span;
+  float* sBq = sAq + bs * bs;
+  const float bs2f = (float)(bs * bs);
   const long HW = (long)H * W;
   const unsigned count = *n_hard;
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
@@ -128,14 +135,14 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     const float* v = vol + fj * D * HW + qj;
     const int d_clamped = wj + (bs - 1 - bs / 2);
     const float m = v[(-1 - idx[pj]) * HW];
-    float x[kMaskWords];
+    float x[WORDS];
 #pragma unroll
-    for (int wd = 0; wd < kMaskWords; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
-    unsigned long long mask[kMaskWords];
+    for (int wd = 0; wd < WORDS; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
+    unsigned long long mask[WORDS];
     bool have_clamped = false;
     int n_cand = 0;
 #pragma unroll
-    for (int wd = 0; wd < kMaskWords; ++wd) {
+    for (int wd = 0; wd < WORDS; ++wd) {
       unsigned long long bits = __ballot(wd * 64 + lane < D && x[wd] >= m - eps);
       const int c0 = d_clamped - wd * 64;                  // bits >= c0 belong to the clamped run
       if (c0 < 64) {
@@ -156,7 +163,9 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
       const float* b = in1 + fj * in1_frame_stride;
       for (int i = lane; i < bs * bs; i += 64) {
         const int bh = i / bs, bw = i - bh * bs;
-        sA[i] = a[(long)clampi(hj + bh - half, 0, H - 1) * W + clampi(wj + bw - half, 0, W - 1)];
+        const float x = a[(long)clampi(hj + bh - half, 0, H - 1) * W + clampi(wj + bw - half, 0, W - 1)];
+        sA[i] = x;
+        sAq[i] = x / bs2f;
       }
       for (int i0 = lane; i0 < bs * span; i0 += 64 * 8) {          // 8 independent loads in flight per lane
         float t[8];
@@ -168,23 +177,42 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (i0 + 64 * k < bs * span) sB[i0 + 64 * k] = t[k];
+          if (i0 + 64 * k < bs * span) {
+            sB[i0 + 64 * k] = t[k];
+            sBq[i0 + 64 * k] = t[k] / bs2f;
+          }
       }
     }
-    // candidates in ascending d: strict > keeps the lowest index on ties
-    bool first = true;
+    // Exact re-scoring, lane <-> candidate (ascending d): every lane runs the reference's serial accumulations for
+    // its own candidate out of LDS (a whole-wave evaluation of one candidate at a time, fed by v_readlane, costs
+    // ~15 us per candidate; this costs ~3 us for all of them).  Then the lowest d among the best exact scores.
+    if (n_cand > 1) {
+      for (int c0 = 0; c0 < n_cand; c0 += 64) {
+        int my_d = -1, k = 0;
 #pragma unroll
-    for (int wd = 0; wd < kMaskWords; ++wd) {
-      unsigned long long mj = mask[wd];
-      while (mj) {
-        const int d = wd * 64 + __ffsll((long long)mj) - 1;
-        mj &= mj - 1;
-        float e = 0.f;
-        if (n_cand > 1)
-          e = bs <= 11 ? ncc_exact_point_wave(sA, sB, bs, span, (D - 1) - d, lane)
-                       : ncc_exact_point_lds(sA, sB, bs, span, (D - 1) - d);
-        if (first || e > eb) { eb = e; ei = d; first = false; }
+        for (int wd = 0; wd < WORDS; ++wd) {
+          unsigned long long mj = mask[wd];
+          while (mj) {
+            const int d = wd * 64 + __ffsll((long long)mj) - 1;
+            mj &= mj - 1;
+            if (k - c0 == lane) my_d = d;
+            ++k;
+          }
+        }
+        float e = -INFINITY;
+        if (my_d >= 0) e = bs == 9 ? ncc_exact_point_lds_bs<9>(sA, sB, sAq, sBq, span, (D - 1) - my_d)
+                                   : ncc_exact_point_lds(sA, sB, bs, span, (D - 1) - my_d);
+        const int n_here = min(64, n_cand - c0);
+        for (int l = 0; l < n_here; ++l) {                 // ascending d: strict > keeps the lowest index on ties
+          const float el = __shfl(e, l);
+          const int dl = __shfl(my_d, l);
+          if (ei == 0x7fffffff || el > eb) { eb = el; ei = dl; }
+        }
       }
+    } else {
+#pragma unroll
+      for (int wd = 0; wd < WORDS; ++wd)
+        if (mask[wd]) ei = min(ei, wd * 64 + __ffsll((long long)mask[wd]) - 1);
     }
     if (lane == 0) {
       idx[pj] = ei;
@@ -220,10 +248,14 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
                        best, D, HW, W, bs, eps, total, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   if (eps < 0.f) return CTD_OK;                            // nothing is marked: plain argmax of the fast volume
-  const size_t lds = sizeof(float) * 4 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
-  if (lds > 64 * 1024) return CTD_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
   const long chunks = (total + 255) / 256;
-  hipLaunchKernelGGL(argmax_resolve_kernel, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
+  auto resolve_sel = [&]() { return D <= 128 ? argmax_resolve_kernel<2> : (D <= 256 ? argmax_resolve_kernel<4> : argmax_resolve_kernel<8>); };
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)resolve_sel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto resolve = D <= 128 ? argmax_resolve_kernel<2> : (D <= 256 ? argmax_resolve_kernel<4> : argmax_resolve_kernel<8>);
+  hipLaunchKernelGGL(resolve, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
                      in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   return CTD_OK;

@@ -82,6 +82,41 @@ __device__ inline float ncc_exact_point_lds(const float* sA, const float* sB, in
   return val;
 }
 
+// compile-time block size: the tap loops are unrolled by rows so that the LDS reads of a row are in flight together
+// sAq / sBq hold the staged values already divided by bs^2 (same correctly rounded quotient, computed once)
+template <int BS>
+__device__ inline float ncc_exact_point_lds_bs(const float* sA, const float* sB, const float* sAq, const float* sBq,
+                                               int span, int off) {
+  float mu0 = 0.f, mu1 = 0.f;
+  for (int bh = 0; bh < BS; ++bh) {
+    float a[BS], b[BS];
+#pragma unroll
+    for (int bw = 0; bw < BS; ++bw) { a[bw] = sAq[bh * BS + bw]; b[bw] = sBq[bh * span + bw + off]; }
+#pragma unroll
+    for (int bw = 0; bw < BS; ++bw) {
+      mu0 += a[bw];
+      mu1 += b[bw];
+    }
+  }
+  float s0 = 0.f, s1 = 0.f, dot = 0.f;
+  for (int bh = 0; bh < BS; ++bh) {
+    float a[BS], b[BS];
+#pragma unroll
+    for (int bw = 0; bw < BS; ++bw) { a[bw] = sA[bh * BS + bw]; b[bw] = sB[bh * span + bw + off]; }
+#pragma unroll
+    for (int bw = 0; bw < BS; ++bw) {
+      const float v0 = a[bw] - mu0;
+      const float v1 = b[bw] - mu1;
+      dot += v0 * v1;
+      s0 += v0 * v0;
+      s1 += v1 * v1;
+    }
+  }
+  float val = 0.f;
+  val += dot / ncc_norm(s0, s1);
+  return val;
+}
+
 // Same value, computed by a whole wavefront: lane t (and t + 64) owns tap t of the window, the per-tap terms
 // are formed in parallel and only the reference's tap-order accumulations run serially, fed by v_readlane.
 // Bit-identical to ncc_exact_point_lds (same operations on the same operands in the same order), but a

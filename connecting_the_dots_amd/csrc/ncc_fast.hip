@@ -44,6 +44,8 @@
 
 namespace ctd {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kFND = 4;        // disparities per lane
 constexpr int kFWaves = 4;     // consumer wavefronts per workgroup (adjacent disparity groups)
 constexpr int kFDG = kFND * kFWaves;   // disparities per workgroup
@@ -392,22 +394,42 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   }
   __syncthreads();
   const long HW = (long)H * W;
-  const long total = (long)s_n * seg;
-  constexpr int kU = 8;
-  for (long e0 = tid; e0 < total; e0 += 256 * kU) {
-    float v[kU];
-    long o[kU];
+  // 32 lanes x 4 pixels span 128 pixels of a row, 8 rows per sweep of the workgroup: no index divisions, 16-byte
+  // accesses wherever the quad lies inside the run and the row starts are 16-byte aligned
+  const int wq = tid & 31, rs = tid >> 5;
+  const bool vec_ok = (D % 4 == 0) && (W % 4 == 0) && (tail % 4 == 0);
+  float* plane = out + ((long)f * D + d) * HW;
+  for (int w0 = 4 * wq; w0 < seg; w0 += 128) {
+    const bool full = vec_ok && w0 + 3 < seg;
+    for (int j0 = rs; j0 < s_n; j0 += 8 * 4) {
+      f32x4 v[4];
+      int hh[4];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const long e = min(e0 + 256 * u, total - 1);
-      const int j = (int)(e / seg), w = (int)(e - (long)j * seg);
-      const int h = s_rows[j];
-      v[u] = run_vals[((long)f * H + h) * D + w + tail];
-      o[u] = ((long)f * D + d) * HW + (long)h * W + w;
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 8 * u, s_n - 1);
+        hh[u] = s_rows[j];
+        const float* src = run_vals + ((long)f * H + hh[u]) * D + w0 + tail;
+        if (full) {
+          v[u] = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[u][i] = w0 + i < seg ? src[i] : __int_as_float(0x7fc00000);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + 8 * u >= s_n) continue;
+        float* dst = plane + (long)hh[u] * W + w0;
+        const bool all_set = v[u][0] == v[u][0] && v[u][1] == v[u][1] && v[u][2] == v[u][2] && v[u][3] == v[u][3];
+        if (full && all_set) {
+          *(f32x4*)dst = v[u];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (w0 + i < seg && v[u][i] == v[u][i]) dst[i] = v[u][i];
+        }
+      }
     }
-#pragma unroll
-    for (int u = 0; u < kU; ++u)
-      if (e0 + 256 * u < total && v[u] == v[u]) out[o[u]] = v[u];
   }
 }
 
@@ -671,7 +693,6 @@ constexpr int kWDmaPerRow = 3 + 3 * 2;        // dwordx4 LDS-DMA instructions pe
 
 // Four floats starting OFF slots after the lane's own quad of a 16-byte aligned LDS array:
 // one or two conflict-free ds_read_b128 (a stride-4 ds_read_b32 pattern is a 4-way bank conflict).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int OFF>
 __device__ inline void lds_read4(const float* arr, int lane, float (&o)[4]) {
