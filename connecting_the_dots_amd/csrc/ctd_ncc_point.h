@@ -117,41 +117,5 @@ __device__ inline float ncc_exact_point_lds_bs(const float* sA, const float* sB,
   return val;
 }
 
-// Same value, computed by a whole wavefront: lane t (and t + 64) owns tap t of the window, the per-tap terms
-// are formed in parallel and only the reference's tap-order accumulations run serially, fed by v_readlane.
-// Bit-identical to ncc_exact_point_lds (same operations on the same operands in the same order), but a
-// few hundred register-only instructions instead of a latency chain of ~650 dependent LDS reads.
-__device__ inline float ncc_exact_point_wave(const float* sA, const float* sB, int bs, int span, int off, int lane) {
-  const int n = bs * bs;                                  // <= 128 taps (bs <= 11)
-  const float bs2 = (float)n;
-  const int t0 = lane, t1 = lane + 64;
-  const bool h0 = t0 < n, h1 = t1 < n;
-  const float a0 = h0 ? sA[t0] : 0.f, a1 = h1 ? sA[t1] : 0.f;
-  const float b0 = h0 ? sB[(t0 / bs) * span + (t0 % bs) + off] : 0.f;
-  const float b1 = h1 ? sB[(t1 / bs) * span + (t1 % bs) + off] : 0.f;
-  const float qa0 = a0 / bs2, qa1 = a1 / bs2, qb0 = b0 / bs2, qb1 = b1 / bs2;
-  float mu0 = 0.f, mu1 = 0.f;
-  for (int t = 0; t < n; ++t) {
-    const int l = t & 63;
-    const float xa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qa0 : qa1), l));
-    const float xb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? qb0 : qb1), l));
-    mu0 += xa;
-    mu1 += xb;
-  }
-  const float va0 = a0 - mu0, va1 = a1 - mu0, vb0 = b0 - mu1, vb1 = b1 - mu1;
-  const float pd0 = va0 * vb0, pd1 = va1 * vb1, pa0 = va0 * va0, pa1 = va1 * va1, pb0 = vb0 * vb0, pb1 = vb1 * vb1;
-  float dot = 0.f, s0 = 0.f, s1 = 0.f;
-  for (int t = 0; t < n; ++t) {
-    const int l = t & 63;
-    dot += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pd0 : pd1), l));
-    s0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pa0 : pa1), l));
-    s1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? pb0 : pb1), l));
-  }
-  const float norm = (float)((double)sqrtf(s0 * s1) + 1e-8);
-  float val = 0.f;
-  val += dot / norm;
-  return val;
-}
-
 }  // namespace ctd
 #endif
