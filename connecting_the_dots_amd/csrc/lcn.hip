@@ -45,12 +45,21 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
   const long base = (long)blockIdx.z * H * W;
   const float* xb = x + base;
 
-  for (int i = tid; i < TRr * TCc; i += kLcnTW * kLcnRows) {
-    int r = i / TCc, c = i - r * TCc;
-    // tiles hanging over the bottom / right edge stage clamped garbage that is never stored
-    int hh = reflect_idx(min(h_lo + r - radius, H - 1 + radius), H);
-    int ww = reflect_idx(min(w_lo + c - radius, W - 1 + radius), W);
-    tile[i] = xb[(long)hh * W + ww];
+  // batches of independent loads: one memory round trip per 8 elements of a thread instead of one each
+  for (int i0 = tid; i0 < TRr * TCc; i0 += kLcnTW * kLcnRows * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + kLcnTW * kLcnRows * u, TRr * TCc - 1);
+      const int r = i / TCc, c = i - r * TCc;
+      // tiles hanging over the bottom / right edge stage clamped garbage that is never stored
+      const int hh = reflect_idx(min(h_lo + r - radius, H - 1 + radius), H);
+      const int ww = reflect_idx(min(w_lo + c - radius, W - 1 + radius), W);
+      t[u] = xb[(long)hh * W + ww];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + kLcnTW * kLcnRows * u < TRr * TCc) tile[i0 + kLcnTW * kLcnRows * u] = t[u];
   }
   __syncthreads();
 

@@ -116,11 +116,20 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     }
     cred[tid] = t;
   }
-  for (int i = tid; i < TRr * TCc; i += kSTW * kSRows) {
-    int r = i / TCc, c = i - r * TCc;
-    int hh = clampi(h_lo + r - half, 0, H - 1);
-    int ww = clampi(xi_lo + x_start + c - half, 0, W - 1);
-    tile[i] = img[(long)hh * W + ww];
+  // batches of independent loads: one memory round trip per 8 elements of a thread instead of one each
+  for (int i0 = tid; i0 < TRr * TCc; i0 += kSTW * kSRows * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + kSTW * kSRows * u, TRr * TCc - 1);
+      const int r = i / TCc, c = i - r * TCc;
+      const int hh = clampi(h_lo + r - half, 0, H - 1);
+      const int ww = clampi(xi_lo + x_start + c - half, 0, W - 1);
+      t[u] = img[(long)hh * W + ww];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + kSTW * kSRows * u < TRr * TCc) tile[i0 + kSTW * kSRows * u] = t[u];
   }
   __syncthreads();
   for (int stride = kSTW * kSRows / 2; stride > 0; stride >>= 1) {   // fixed tree: same bits in every workgroup
