@@ -154,6 +154,16 @@ int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, i
   return lcn_f32(x, y, std_out, N, H, W, radius, eps, (hipStream_t)stream);
 }
 
+int ctd_lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W, int kernel_size, float eps,
+                        int device, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || kernel_size < 0 || N > 65535) return CTD_ERR_INVALID_ARG;
+  if (N == 0) return CTD_OK;
+  if (!img || !out || !out_std) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return lcn_datagen_f32(img, out, out_std, N, H, W, kernel_size, eps, (hipStream_t)stream);
+}
+
 static bool photo_shape_ok(int B, int C, int H, int W, int bs, int type) {
   return B >= 0 && C > 0 && H > 0 && W > 0 && bs > 0 && type >= 0 && type <= 3 &&
          (double)B * C * H * W < 2147483648.0;                 // int indices in the reference (ext.h:220-235)

@@ -68,6 +68,9 @@ int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, f
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 
+int lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W, int ks, float eps,
+                    hipStream_t stream);
+
 // losses.hip
 int disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bf, hipStream_t s);
 int disp_to_depth_bwd_f32(const float* disp, const float* go, float* gi, long n, float bf, hipStream_t s);

@@ -125,4 +125,68 @@ int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radi
   return CTD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Data-generation variant: data/lcn/lcn.pyx:16-58 (`lcn.normalize(img, kernel_size, epsilon)`, used on the
+// ambient-gradient image in data/create_syn_data.py:181).  Two-pass window mean / standard deviation over
+// (2ks+1)^2 taps accumulated in f32 in row-major tap order (bit-identical to the Cython loop), output
+// (x - mean) / (std + eps) and the RAW std; a border of width ks stays zero in both outputs.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kLdTW = 64, kLdTH = 8;
+
+__global__ __launch_bounds__(256) void lcn_datagen_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                          float* __restrict__ out_std, int H, int W, int ks, float eps) {
+  extern __shared__ float lds_f[];
+  const int TC = kLdTW + 2 * ks, TR = kLdTH + 2 * ks;
+  const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * kLdTW, y0 = blockIdx.y * kLdTH;
+  const long base = (long)blockIdx.z * H * W;
+  for (int i0 = threadIdx.x; i0 < TR * TC; i0 += 256 * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + 256 * u, TR * TC - 1);
+      const int r = i / TC, c = i - r * TC;
+      t[u] = img[base + (long)clampi(y0 + r - ks, 0, H - 1) * W + clampi(x0 + c - ks, 0, W - 1)];   // clamped taps are
+    }                                                                                                // only read by border pixels
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 256 * u < TR * TC) lds_f[i0 + 256 * u] = t[u];
+  }
+  __syncthreads();
+  const float num = (float)((ks * 2 + 1) * (ks * 2 + 1));            // lcn.pyx:33
+#pragma unroll
+  for (int k = 0; k < kLdTH / 4; ++k) {
+    const int ty = ty0 + 4 * k, x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) continue;
+    float o = 0.f, sd = 0.f;
+    if (y >= ks && y < H - ks && x >= ks && x < W - ks) {
+      const float* win = lds_f + ty * TC + tx;                       // top-left tap of the window
+      float mean = 0.f;
+      for (int i = 0; i <= 2 * ks; ++i)
+        for (int j = 0; j <= 2 * ks; ++j) mean += win[i * TC + j];
+      mean = mean / num;
+      float acc = 0.f;
+      for (int i = 0; i <= 2 * ks; ++i)
+        for (int j = 0; j <= 2 * ks; ++j) {
+          const float d = win[i * TC + j] - mean;
+          acc = acc + d * d;
+        }
+      sd = sqrtf(acc / num);
+      o = (win[ks * TC + ks] - mean) / (sd + eps);
+    }
+    out[base + (long)y * W + x] = o;
+    out_std[base + (long)y * W + x] = sd;
+  }
+}
+
+int lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W, int ks, float eps,
+                    hipStream_t stream) {
+  const size_t lds = sizeof(float) * (size_t)(kLdTW + 2 * ks) * (kLdTH + 2 * ks);
+  if (lds > 64 * 1024) return CTD_ERR_UNSUPPORTED;
+  dim3 grid(ceil_div(W, kLdTW), ceil_div(H, kLdTH), N);
+  hipLaunchKernelGGL(lcn_datagen_kernel, grid, dim3(256), lds, stream, img, out, out_std, H, W, ks, eps);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
 }  // namespace ctd

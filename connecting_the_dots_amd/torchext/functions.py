@@ -272,6 +272,23 @@ def lcn(data, radius, epsilon):
     return y, std
 
 
+def lcn_normalize(img, kernel_size=4, epsilon=0.01):
+    """Additive: the data generator's LCN, `lcn.normalize(img, kernel_size, epsilon)` of data/lcn/lcn.pyx:16-58
+    (two-pass mean / std, zero border of width kernel_size, returns (lcn, raw std)); img [H,W] or [N,H,W]."""
+    _check(img, "img", (torch.float32,))
+    squeeze = img.dim() == 2
+    a = img.unsqueeze(0) if squeeze else img
+    if a.dim() != 3:
+        raise RuntimeError("lcn_normalize expects [H,W] or [N,H,W]")
+    N, H, W = a.shape
+    dev = a.device
+    out, std = torch.empty_like(a), torch.empty_like(a)
+    st = _lib.lib().ctd_lcn_datagen_f32(_ptr(a), _ptr(out), _ptr(std), N, H, W, int(kernel_size), float(epsilon), dev.index,
+                                        _stream(dev))
+    _lib.check(st, "lcn_normalize")
+    return (out[0], std[0]) if squeeze else (out, std)
+
+
 # --------------------------------------------------------------------------------------
 # Photometric block loss (reference: PhotometricLossFunction, functions.py:79-118)
 # --------------------------------------------------------------------------------------

@@ -163,6 +163,12 @@ int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_fra
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
                 float eps, int device, void* stream);
 
+/* Data-generation variant, data/lcn/lcn.pyx:16-58 (`lcn.normalize(img, kernel_size, epsilon)`): two-pass window mean
+ * / std in f32 in the Cython loop's tap order (bit-identical), out = (x - mean) / (std + eps), out_std = raw std, a
+ * border of width kernel_size stays zero.  img, out, out_std [N][H][W]. */
+int ctd_lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W,
+                        int kernel_size, float eps, int device, void* stream);
+
 /* --------------------------------------------------------------------------------------
  * DispToDepth.tforward, model/networks.py:313-321, and its backward.
  *   depth = (baseline*focal) / (relu(disp) + 1e-12)

@@ -49,3 +49,23 @@ def test_lcn_errors(te):
         te.lcn(torch.rand(1, 1, 4, 8).cuda(), 4, 0.05)     # radius >= H
     with pytest.raises(RuntimeError):
         te.lcn(torch.rand(1, 2, 8, 8).cuda(), 2, 0.05)     # C != 1
+
+
+def test_lcn_datagen_variant_bit_exact(oracle):
+    """data/lcn/lcn.pyx:16-58 (`lcn.normalize`): golden from the cythonized reference, plus the oracle on a batch of
+    tile-straddling sizes; the zero border of width kernel_size is part of the contract"""
+    from connecting_the_dots_amd import torchext as te
+    g = golden("lcn_datagen")
+    img = torch.from_numpy(g["img"]).cuda()
+    for ks, eps in ((5, 0.05), (2, 0.1)):                  # the parameters the goldens were generated with
+        y, s = te.lcn_normalize(img, ks, eps)
+        ry, rs = oracle.lcn_datagen(g["img"], ks, eps)
+        assert np.array_equal(y.cpu().numpy(), ry) and np.array_equal(s.cpu().numpy(), rs)
+        assert np.array_equal(y.cpu().numpy(), g["y_%d" % ks]) and np.array_equal(s.cpu().numpy(), g["std_%d" % ks])
+        assert float(y[:ks].abs().max()) == 0 and float(y[:, :ks].abs().max()) == 0 and float(s[-ks:].abs().max()) == 0
+    rs_ = np.random.RandomState(4)
+    batch = rs_.rand(3, 37, 150).astype(np.float32)
+    y, s = te.lcn_normalize(torch.from_numpy(batch).cuda(), 5, 0.1)
+    for k in range(3):
+        ry, rstd = oracle.lcn_datagen(batch[k], 5, 0.1)
+        assert np.array_equal(y[k].cpu().numpy(), ry) and np.array_equal(s[k].cpu().numpy(), rstd)
