@@ -149,3 +149,33 @@ def test_fast_constant_images(te, oracle):
     b[0, 10, 20] = 1.0
     vol = te.xcorrvol_batch(dev(a), dev(b), 16, 9, algo="fast")[0].cpu().numpy()
     assert np.array_equal(vol, oracle.xcorrvol(a[0], b, 16, 9))
+
+
+def test_fast_random_shapes_vs_exact(te):
+    """seeded sweep over shapes / channel counts / block sizes / input kinds (flat halves, DC offsets, dot patterns,
+    per-frame patterns; W not a multiple of 4 takes the fallback kernels): volume within tolerance of the
+    reference-order kernel and, for C == 1, re-ranked indices identical to the fused exact argmax
+    (tools/fuzz_fast.py runs the same check over hundreds of configurations)"""
+    rs = np.random.RandomState(11)
+    for it in range(24):
+        C = int(rs.choice([1, 1, 1, 2, 3])); N = int(rs.randint(1, 4)); bs = int(rs.choice([9, 9, 9, 7, 5, 3]))
+        H = int(rs.randint(1, 90)); W = int(rs.choice([rs.randint(1, 70), 4 * rs.randint(1, 100), rs.randint(60, 400)]))
+        D = int(rs.choice([1, 2, rs.randint(1, 40), rs.randint(40, 200)]))
+        per_frame = bool(rs.rand() < 0.3)
+        kind = rs.choice(["normal", "flat", "offset", "dots"])
+        a = rs.randn(N, C, H, W).astype(np.float32)
+        b = rs.randn(N if per_frame else 1, C, H, W).astype(np.float32)
+        if kind == "flat":
+            a[:, :, : H // 2] = 0.5
+            b[:, :, :, : max(1, W // 3)] = -1.0
+        if kind == "offset":
+            a, b = a * 5 + 100, b * 9 + 40
+        if kind == "dots":
+            b = (rs.rand(*b.shape) < 0.1).astype(np.float32)
+        A, B = dev(a), dev(b if per_frame else b[0])
+        ex = te.xcorrvol_batch(A, B, D, bs, algo="exact")
+        fa = te.xcorrvol_batch(A, B, D, bs, algo="fast")
+        cfg = (N, C, H, W, D, bs, per_frame, str(kind))
+        assert bool(((fa - ex).abs() <= ex.abs() * 1e-5 + 1e-6).all()), cfg
+        if C == 1:
+            assert torch.equal(te.xcorrvol_argmax(A, B, D, bs, algo="fast")[0], te.xcorrvol_argmax(A, B, D, bs, algo="exact")[0]), cfg
