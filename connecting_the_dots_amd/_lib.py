@@ -6,8 +6,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# CTD_HIP_LIB: alternative build of the same ABI (kernel experiments); default is the in-tree library
-LIB_PATH = os.environ.get("CTD_HIP_LIB") or os.path.join(_PKG, "libctd_hip.so")
+LIB_PATH = os.path.join(_PKG, "libctd_hip.so")
 
 _c_int, _c_long, _c_float, _c_size_t, _vp = (ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t,
                                              ctypes.c_void_p)
@@ -30,6 +29,9 @@ SIGNATURES = {
     "ctd_xcorrvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 7 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_xcorrvol_f64": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_argmax_disp_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_int, _vp]),
+    "ctd_xcorrvol_rank_supported": (_c_int, [_c_int] * 5),
+    "ctd_xcorrvol_rank_layout": (_c_int, [_c_int] * 5 + [ctypes.POINTER(_c_size_t)]),
+    "ctd_xcorrvol_argmax_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 7 + [_c_float, _vp, _c_size_t,
                                                                                           _c_int, _vp]),
     "ctd_photometric_fwd_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),

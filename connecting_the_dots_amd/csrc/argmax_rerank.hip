@@ -20,14 +20,9 @@ namespace ctd {
 // Pass 1: one coalesced sweep over d, 4 adjacent pixels per thread (16-byte loads), branch-free tracking of
 // the best score / index and of the runner-up score.  Pixels whose runner-up is within eps of the best are
 // marked (idx = -1 - argmax) for pass 2; all others are final.
-#ifndef CTD_SCAN_BATCH
-#define CTD_SCAN_BATCH 8
-#endif
-#ifndef CTD_SCAN_WAVES
-#define CTD_SCAN_WAVES 5
-#endif
+constexpr int kScanBatch = 8;
 template <int PX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTD_SCAN_WAVES, 8))) void argmax_scan_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void argmax_scan_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
                                                           float* __restrict__ best, int D, long HW, int W,
                                                           int bs, float eps, long total_threads,
                                                           unsigned* __restrict__ n_hard,
@@ -46,7 +41,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTD_SCAN_WA
   for (int k = 0; k < PX; ++k) { v0[k] = -INFINITY; v1[k] = -INFINITY; i0[k] = 0; dc[k] = w0 + k + (bs - 1 - bs / 2); }
   // explicit batches of kBatch independent loads (the compiler otherwise waits for each plane before
   // requesting the next); streamed once, so non-temporal
-  constexpr int kBatch = CTD_SCAN_BATCH;
+  constexpr int kBatch = kScanBatch;
   const bool wave_masks = __any(dc[0] < D - 1);
   for (int d0 = 0; d0 < D; d0 += kBatch) {
     float x[kBatch][PX];
@@ -100,14 +95,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CTD_SCAN_WA
   }
 }
 
-// Pass 2: one wavefront per marked pixel of the work list.  Lane <-> disparity collects the pixel's candidate
-// set with one round of loads (scores within eps of the best; the run of disparities whose window is clamped
-// to column 0 counted once, lowest d); a single candidate is final, otherwise the frame window and the
-// reachable pattern rows are staged in LDS and the wave re-scores each candidate in reference order.
+// Merge of the per-group partials written by the volume kernel's in-kernel ranking (ncc_fast.hip, t256_consume):
+// 4 adjacent pixels per thread, two 16-byte loads per disparity group.  Keys are scores whose 4 low mantissa bits hold
+// 15 - (disparity within the group), so the maximum carries its index; a listed fully clamped run contributes its exact
+// value (run_vals) as one more candidate at its first disparity.  A pixel whose runner-up lies within eps (+ the key
+// truncation) of its best goes to the resolve pass (work list); so does one whose patched scores did not fit the
+// patch list (dirty byte set by the fix-up pass).  The dirty bytes are rewritten as "is on the work list" flags for
+// rank_patch_check_kernel.
+__global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
+                                                         int n_dg, int dg_size, const float* __restrict__ run_flag,
+                                                         long run_flag_frame_stride, long run_flag_row_stride,
+                                                         const float* __restrict__ run_vals,
+                                                         unsigned char* __restrict__ dirty,
+                                                         int64_t* __restrict__ idx, float* __restrict__ best, int D,
+                                                         int H, int W, int tail, float eps, long total_quads,
+                                                         unsigned* __restrict__ n_hard, int64_t* __restrict__ hard_list) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total_quads) return;
+  const long HW = (long)H * W;
+  const long p0 = t * 4;
+  const long f = p0 / HW, q0 = p0 - f * HW;
+  const int h = (int)(q0 / W), w0 = (int)(q0 - (long)h * W);
+  const float* a0 = k0 + f * n_dg * HW + q0;
+  const float* a1 = k1 + f * n_dg * HW + q0;
+  float M[4], R[4];
+  int gi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { M[k] = -INFINITY; R[k] = -INFINITY; gi[k] = 0; }
+  constexpr int kB = 5;                                       // groups per batch of independent loads
+  for (int g0 = 0; g0 < n_dg; g0 += kB) {
+    f4 x0[kB], x1[kB];
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const long o = (long)min(g0 + u, n_dg - 1) * HW;
+      x0[u] = __builtin_nontemporal_load((const f4*)(a0 + o));
+      x1[u] = __builtin_nontemporal_load((const f4*)(a1 + o));
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      if (g0 + u >= n_dg) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float top = x0[u][k], sec = x1[u][k];
+        // runner-up of the union of {M >= R} and {top >= sec}
+        R[k] = fmaxf(fmaxf(fminf(M[k], top), R[k]), sec);
+        gi[k] = top > M[k] ? g0 + u : gi[k];                    // strict >: the lower group keeps a tie
+        M[k] = fmaxf(M[k], top);
+      }
+    }
+  }
+  const float rf = w0 + tail < D ? run_flag[f * run_flag_frame_stride + h * run_flag_row_stride] : 0.f;
+  const bool run_listed = rf != rf;                            // NaN deviation: the run's window is listed
+  f4 bq;
+  const unsigned dirty4 = *(const unsigned*)(dirty + p0);
+  unsigned listed4 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int w = w0 + k;
+    int d = gi[k] * dg_size + 15 - (__float_as_int(M[k]) & 15);
+    float b = __int_as_float((__float_as_int(M[k]) & ~15) | 8);  // centre of the truncation interval
+    float m = M[k], r = R[k];
+    if (run_listed && w + tail < D) {
+      const float c = run_vals[(f * H + h) * D + w + tail];
+      if (c == c) {                                             // not NaN: the run's exact score competes at its first disparity
+        if (c > m) { r = m; m = c; b = c; d = w + tail; }
+        else r = fmaxf(r, c);
+      }
+    }
+    const float margin = eps + 4e-6f * fmaxf(1.f, fabsf(m));    // two keys, each truncated by <= 2^-19 relative
+    // m == -inf: every score of the pixel was left to the fix-up pass
+    const bool hard = eps >= 0.f && (((dirty4 >> (8 * k)) & 0xff) != 0 || r >= m - margin || !(m > -INFINITY));
+    idx[p0 + k] = d;
+    bq[k] = b;
+    if (hard) {
+      hard_list[atomicAdd(n_hard, 1u)] = p0 + k;
+      listed4 |= 1u << (8 * k);
+    }
+  }
+  *(unsigned*)(dirty + p0) = listed4;
+  *(f4*)(best + p0) = bq;
+}
+
+// Scores the fix-up pass recomputed (listed windows) were NaN for the in-kernel ranking.  A pixel whose merged best
+// is not clear of such a score by the margin joins the work list (once: its flag byte is claimed atomically).
+__global__ __launch_bounds__(256) void rank_patch_check_kernel(const unsigned* __restrict__ n_patches,
+                                                               const unsigned long long* __restrict__ patches,
+                                                               unsigned capacity, const float* __restrict__ best,
+                                                               unsigned* __restrict__ flags, float eps,
+                                                               unsigned* __restrict__ n_hard,
+                                                               int64_t* __restrict__ hard_list) {
+  const unsigned n = min(*n_patches, capacity);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned long long e = patches[i];
+    const unsigned pix = (unsigned)(e >> 32);
+    const float val = __int_as_float((int)(unsigned)e), m = best[pix];
+    const float margin = eps + 4e-6f * fmaxf(1.f, fabsf(m));
+    if (!(val < m - margin)) {                                 // also NaN
+      const unsigned bit = 1u << (8 * (pix & 3));
+      if ((atomicOr(flags + (pix >> 2), bit) & bit) == 0) hard_list[atomicAdd(n_hard, 1u)] = pix;
+    }
+  }
+}
+
+// Pass 2: one wavefront per pixel of the work list.  VOL: lane <-> disparity collects the pixel's candidate set from
+// the (patched) fast volume with one round of loads (scores within eps of the best; the run of disparities whose
+// window is clamped to column 0 counted once, lowest d); a single candidate is final, otherwise the frame window
+// and the reachable pattern rows are staged in LDS and the wave re-scores each candidate in reference order.
+// !VOL (no volume was materialised): every disparity up to the start of the clamped run is a candidate.
 constexpr int kMaskWords = 8;            // at most 512 disparities per candidate mask
 
+__device__ inline float wave_maxf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
 // WORDS = 64-disparity words of the candidate mask (2 for D <= 128 ... 8 for D <= 512)
-template <int WORDS>
+template <int WORDS, bool VOL>
 __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __restrict__ vol,
                                                              const float* __restrict__ in0,
                                                              const float* __restrict__ in1, long in1_frame_stride,
@@ -132,29 +237,43 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     const long pj = hard_list[item];                       // wave-uniform from here on
     const long fj = pj / HW, qj = pj - fj * HW;
     const int hj = (int)(qj / W), wj = (int)(qj - (long)hj * W);
-    const float* v = vol + fj * D * HW + qj;
+    const float* v = VOL ? vol + fj * D * HW + qj : nullptr;
     const int d_clamped = wj + (bs - 1 - bs / 2);
-    const float m = v[(-1 - idx[pj]) * HW];
-    float x[WORDS];
-#pragma unroll
-    for (int wd = 0; wd < WORDS; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
     unsigned long long mask[WORDS];
-    bool have_clamped = false;
     int n_cand = 0;
+    if constexpr (VOL) {
+      float x[WORDS];
 #pragma unroll
-    for (int wd = 0; wd < WORDS; ++wd) {
-      unsigned long long bits = __ballot(wd * 64 + lane < D && x[wd] >= m - eps);
-      const int c0 = d_clamped - wd * 64;                  // bits >= c0 belong to the clamped run
-      if (c0 < 64) {
-        const unsigned long long run = c0 <= 0 ? bits : bits & ~((1ull << c0) - 1ull);
-        bits &= ~run;
-        if (!have_clamped && run) {
-          bits |= run & (0ull - run);                      // lowest disparity of the run stands for all of it
-          have_clamped = true;
+      for (int wd = 0; wd < WORDS; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
+      // best fast score; of the clamped run (copies of one score) only the first element takes part
+      float m = -INFINITY;
+#pragma unroll
+      for (int wd = 0; wd < WORDS; ++wd)
+        if (wd * 64 + lane < D && wd * 64 + lane <= d_clamped) m = fmaxf(m, x[wd]);
+      m = wave_maxf(m);
+      bool have_clamped = false;
+#pragma unroll
+      for (int wd = 0; wd < WORDS; ++wd) {
+        unsigned long long bits = __ballot(wd * 64 + lane < D && x[wd] >= m - eps);
+        const int c0 = d_clamped - wd * 64;                  // bits >= c0 belong to the clamped run
+        if (c0 < 64) {
+          const unsigned long long run = c0 <= 0 ? bits : bits & ~((1ull << c0) - 1ull);
+          bits &= ~run;
+          if (!have_clamped && run) {
+            bits |= run & (0ull - run);                      // lowest disparity of the run stands for all of it
+            have_clamped = true;
+          }
         }
+        mask[wd] = bits;
+        n_cand += __popcll(bits);
       }
-      mask[wd] = bits;
-      n_cand += __popcll(bits);
+    } else {
+#pragma unroll
+      for (int wd = 0; wd < WORDS; ++wd) {
+        const int last = min(D - 1, d_clamped) - wd * 64;    // candidates: bits 0 .. last of this word
+        mask[wd] = last < 0 ? 0ull : (last >= 63 ? ~0ull : ((1ull << (last + 1)) - 1ull));
+        n_cand += __popcll(mask[wd]);
+      }
     }
     float eb = 0.f;
     int ei = 0x7fffffff;
@@ -192,6 +311,7 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
 #pragma unroll
         for (int wd = 0; wd < WORDS; ++wd) {
           unsigned long long mj = mask[wd];
+          if (k + __popcll(mj) <= c0 || k >= c0 + 64) { k += __popcll(mj); continue; }   // word outside this round
           while (mj) {
             const int d = wd * 64 + __ffsll((long long)mj) - 1;
             mj &= mj - 1;
@@ -202,12 +322,11 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
         float e = -INFINITY;
         if (my_d >= 0) e = bs == 9 ? ncc_exact_point_lds_bs<9>(sA, sB, sAq, sBq, span, (D - 1) - my_d)
                                    : ncc_exact_point_lds(sA, sB, bs, span, (D - 1) - my_d);
-        const int n_here = min(64, n_cand - c0);
-        for (int l = 0; l < n_here; ++l) {                 // ascending d: strict > keeps the lowest index on ties
-          const float el = __shfl(e, l);
-          const int dl = __shfl(my_d, l);
-          if (ei == 0x7fffffff || el > eb) { eb = el; ei = dl; }
-        }
+        // best exact score of the round, lowest d among its holders; strict > across rounds keeps the lowest index on ties
+        const float em = wave_maxf(e);
+        const unsigned long long holders = __ballot(my_d >= 0 && e == em);
+        const int dl = __shfl(my_d, holders ? __ffsll((long long)holders) - 1 : 0);
+        if (ei == 0x7fffffff || em > eb) { eb = em; ei = dl; }
       }
     } else {
 #pragma unroll
@@ -216,15 +335,50 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     }
     if (lane == 0) {
       idx[pj] = ei;
-      if (best) best[pj] = v[(long)ei * HW];
+      if (best) {
+        if constexpr (VOL) best[pj] = v[(long)ei * HW];
+        else if (n_cand > 1) best[pj] = eb;                  // no fast score exists: the reference-order one
+      }
     }
   }
 }
 
-#ifndef CTD_RESOLVE_BLOCKS
-#define CTD_RESOLVE_BLOCKS 1024
-#endif
-constexpr long kResolveBlocks = CTD_RESOLVE_BLOCKS;
+constexpr long kResolveBlocks = 1024;
+
+template <bool VOL>
+static int launch_resolve(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
+                          float* best, long total, int D, int H, int W, int bs, float eps, const unsigned* n_hard,
+                          const int64_t* hard_list, hipStream_t stream) {
+  const size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  const long chunks = (total + 255) / 256;
+  auto resolve = D <= 128 ? argmax_resolve_kernel<2, VOL> : (D <= 256 ? argmax_resolve_kernel<4, VOL> : argmax_resolve_kernel<8, VOL>);
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(resolve, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
+                     in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int rank_merge_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                   int64_t* idx, float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream) {
+  if (D > kMaskWords * 64 || W % 4 != 0) return CTD_ERR_UNSUPPORTED;
+  const long total = (long)frames * H * W;
+  float* scratch_best = best ? best : rp.best_scratch;
+  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0, rp.k1,
+                     rp.n_dg, rp.dg_size, rp.run_flag, rp.run_flag_frame_stride, rp.run_flag_row_stride, rp.run_vals,
+                     rp.dirty, idx, scratch_best, D, H, W, bs - 1 - bs / 2, eps, total / 4, rp.n_hard, rp.hard_list);
+  CTD_LAUNCH_CHECK();
+  if (eps < 0.f) return CTD_OK;                            // nothing is listed: plain argmax of the fast scores
+  hipLaunchKernelGGL(rank_patch_check_kernel, dim3(512), dim3(256), 0, stream, rp.n_patches, rp.patches, rp.patch_capacity,
+                     scratch_best, (unsigned*)rp.dirty, eps, rp.n_hard, rp.hard_list);
+  CTD_LAUNCH_CHECK();
+  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, rp.n_hard,
+                                    rp.hard_list, stream)
+             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, rp.n_hard,
+                                     rp.hard_list, stream);
+}
 
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
@@ -248,17 +402,7 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
                        best, D, HW, W, bs, eps, total, n_hard, hard_list);
   CTD_LAUNCH_CHECK();
   if (eps < 0.f) return CTD_OK;                            // nothing is marked: plain argmax of the fast volume
-  const size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
-  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
-  const long chunks = (total + 255) / 256;
-  auto resolve_sel = [&]() { return D <= 128 ? argmax_resolve_kernel<2> : (D <= 256 ? argmax_resolve_kernel<4> : argmax_resolve_kernel<8>); };
-  if (lds > 64 * 1024)
-    CTD_HIP_TRY(hipFuncSetAttribute((const void*)resolve_sel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  auto resolve = D <= 128 ? argmax_resolve_kernel<2> : (D <= 256 ? argmax_resolve_kernel<4> : argmax_resolve_kernel<8>);
-  hipLaunchKernelGGL(resolve, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
-                     in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
-  CTD_LAUNCH_CHECK();
-  return CTD_OK;
+  return launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, n_hard, hard_list, stream);
 }
 
 }  // namespace ctd

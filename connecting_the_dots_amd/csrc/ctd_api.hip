@@ -94,7 +94,7 @@ int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, 
                          (hipStream_t)stream);
   if (algo == CTD_NCC_FAST)
     return ncc_fast_f32(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
-                        (hipStream_t)stream);
+                        nullptr, (hipStream_t)stream);
   return CTD_ERR_INVALID_ARG;
 }
 
@@ -121,6 +121,25 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
   return argmax_disp_f32(vol, idx, best, frames, D, H, W, (hipStream_t)stream);
 }
 
+int ctd_xcorrvol_rank_supported(int C, int H, int W, int D, int block_size) {
+  return vol_shape_ok(1, C, H, W, D, block_size) && ncc_fast_rank_supported(C, H, W, D, block_size) ? 1 : 0;
+}
+
+int ctd_xcorrvol_rank_layout(int frames, int H, int W, int D, int per_frame_pattern, size_t* offsets) {
+  if (!offsets || frames <= 0 || !vol_shape_ok(frames, 1, H, W, D, 9)) return CTD_ERR_INVALID_ARG;
+  ncc_fast_rank_offsets(frames, H, W, D, per_frame_pattern != 0, offsets);
+  return CTD_OK;
+}
+
+size_t ctd_xcorrvol_argmax_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo) {
+  size_t base = ctd_xcorrvol_workspace_bytes(frames, C, H, W, D, block_size, algo);
+  if (base == 0 || algo != CTD_NCC_FAST) return base;
+  // old path: work list behind a 16-byte counter at the start of the workspace
+  size_t need = 16 + sizeof(int64_t) * (size_t)frames * H * W;
+  if (ncc_fast_rank_supported(C, H, W, D, block_size)) need = ncc_fast_rank_workspace_bytes(frames, H, W, D, true);
+  return need > base ? need : base;
+}
+
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
                             float* best, int frames, int C, int H, int W, int D, int block_size, int algo,
                             float rerank_eps, void* workspace, size_t workspace_bytes, int device, void* stream) {
@@ -134,9 +153,19 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
                                 workspace_bytes, (hipStream_t)stream);
   if (algo == CTD_NCC_FAST) {
-    if (!vol_out || rerank_eps != rerank_eps) return CTD_ERR_INVALID_ARG;   // the fast path ranks a materialised volume; eps < 0 disables the re-rank
+    if (rerank_eps != rerank_eps) return CTD_ERR_INVALID_ARG;              // eps < 0 disables the re-rank
+    if (ncc_fast_rank_supported(1, H, W, D, block_size) && ((uintptr_t)vol_out) % 16 == 0) {
+      // ranked inside the volume kernel: partial top-2 per disparity group, merged here; no pass over the volume
+      RankPlan rp;
+      int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
+                            workspace_bytes, &rp, (hipStream_t)stream);
+      if (st) return st;
+      return rank_merge_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
+                            (hipStream_t)stream);
+    }
+    if (!vol_out) return CTD_ERR_INVALID_ARG;                              // this shape ranks a materialised volume
     int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
-                          workspace_bytes, (hipStream_t)stream);
+                          workspace_bytes, nullptr, (hipStream_t)stream);
     if (st) return st;
     return argmax_rerank_f32(vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
                              workspace, workspace_bytes, /*counter_cleared=*/true, (hipStream_t)stream);

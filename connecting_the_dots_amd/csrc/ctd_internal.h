@@ -21,14 +21,36 @@ int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stri
 int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream);
 
 // ncc_fast.hip
+// Buffers of the in-kernel ranking (all inside the caller's workspace, laid out by ncc_fast_f32).
+struct RankPlan {
+  float *k0, *k1;             // [frames][n_dg][H][W] largest / second largest score KEY of every disparity group
+  int n_dg, dg_size;          // disparity groups, disparities per group; key = score with low 4 mantissa bits = 15 - d % dg_size
+  unsigned char* dirty;       // [frames][H][W] in: 1 = a patched score of this pixel did not fit the patch list;
+                              // out (rank_merge_kernel): 1 = pixel is on the work list
+  const unsigned* n_patches;  // scores recomputed by the fix-up pass outside the runs: (flat pixel << 32 | f32 bits)
+  const unsigned long long* patches;
+  unsigned patch_capacity;
+  float* best_scratch;        // [frames][H][W] merged best score when the caller does not ask for it
+  unsigned* n_hard;           // work list of the pixels the exact re-scoring has to settle
+  int64_t* hard_list;
+  const float* run_flag;      // pattern deviation plane at the fully clamped run's window column: sign bit = listed
+  long run_flag_frame_stride, run_flag_row_stride;
+  const float* run_vals;      // [frames][H][D] exact score of a listed run, indexed by its first disparity
+  size_t bytes;               // workspace bytes up to the end of these buffers
+};
 size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
+bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs);
+size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern);
+void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off);
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
-                 int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream);
 
 // argmax_rerank.hip
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
                       size_t workspace_bytes, bool counter_cleared, hipStream_t stream);
+int rank_merge_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                   int64_t* idx, float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream);
 
 // photometric.hip
 int photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,

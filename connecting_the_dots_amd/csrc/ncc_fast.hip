@@ -32,15 +32,6 @@
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
 
-#ifndef CTD_FIXUP_BLOCKS
-#define CTD_FIXUP_BLOCKS 2048
-#endif
-#ifndef CTD_ABLATE2
-#define CTD_ABLATE2 0   // bit 0: no DPP combine, bit 1: no finalize, bit 2: no pattern-side LDS reads, bit 3: no vertical tree
-#endif
-#ifndef CTD_ABLATE
-#define CTD_ABLATE 0   // timing experiments only (tools); 0 in every shipped build
-#endif
 
 namespace ctd {
 
@@ -61,7 +52,7 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
 constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
-constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(kPairLimit) - 1
+constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
 // out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
@@ -78,6 +69,7 @@ struct PrepassJob {
   int col_lo, col_hi;
   unsigned* n_runs;
   unsigned long long* run_rows;
+  unsigned char* dirty;       // job a only, may be null: per-pixel flag byte of the ranking passes, cleared here
 };
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
@@ -96,6 +88,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   unsigned long long* __restrict__ flag_list = jp.flag_list;
   unsigned* __restrict__ n_runs = jp.n_runs;
   unsigned long long* __restrict__ run_rows = jp.run_rows;
+  unsigned char* __restrict__ dirty = jp.dirty;
   if ((int)blockIdx.x * kSTW >= W_out) return;
   extern __shared__ double lds_d[];
   __shared__ double cred[kSTW * kSRows];
@@ -175,20 +168,22 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     double mean = s1 / n;
     double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
     // Windows whose outputs the fast kernel cannot deliver within tolerance are listed for ncc_fixup_kernel
-    // (see there):
+    // (see there), which recomputes EVERY output they take part in:
     //  * deviation small against the offset from the centring constant: cov = S_ab - n*ma*mb cancels in f32;
     //  * (nearly) flat window, deviation below 2e-4 of its mean: the reference's own value is then decided by
-    //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it.  Marked by
-    //    a set sign bit in the deviation plane so that every pair it takes part in is recomputed.
+    //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it.
+    // A listed window's deviation is stored as NaN: the fast kernels then produce NaN for exactly the outputs the
+    // fix-up pass overwrites, and a NaN score never enters the in-kernel ranking (t256_consume).
     const double mc = mean - (double)cval;
     const bool flat = 4e-8 * n * mean * mean > var;
     const bool listed = flat || n * mc * mc > kFlagRatio * var;
     const float dev = (float)sqrt(var > 0 ? var : 0.0);
     const long o = ((long)img_idx * H + h) * W_out + xi;
-    out_mean[o] = (float)mc;
-    out_dev[o] = flat ? -dev : dev;
-    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     const int col = xi + x_start;
+    out_mean[o] = (float)mc;
+    out_dev[o] = listed ? __int_as_float(0x7fc00000) : dev;
+    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
+    if (dirty && col >= 0 && col < W) dirty[((long)img_idx * H + h) * W + col] = 0;
     if (listed && col >= col_lo && col < col_hi) {
       flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)img_idx << 40) | ((unsigned long long)h << 20) |
                                          (unsigned long long)(col + 0x80000);
@@ -203,10 +198,10 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
 // centred by one constant per image, so |fast - exact| <~ c * 2^-24 * sqrt(Fa * Fb) with
 // F = 1 + n*(window mean - centring)^2 / (sum of squared deviations) per window and c <= ~6 (ten f32
 // roundings along the longest summation path).  The contract |a-b| <= 1e-5|b| + 1e-6 therefore holds
-// whenever Fa * Fb <= kPairLimit; LCN'd input has F ~ 1 except in flat regions and in the low-variance
-// windows clamped to column 0.  The pre-pass lists every window with F > sqrt(kPairLimit); this kernel
-// visits the listed windows, checks each (frame window, pattern window) pair they take part in and
-// recomputes the offending outputs in the reference's operation order (bit-identical to CTD_NCC_EXACT).
+// whenever Fa * Fb <= 8; LCN'd input has F ~ 1 except in flat regions and in the low-variance windows clamped
+// to column 0.  The pre-pass lists every window with F > sqrt(8) (and marks it with a NaN deviation); this kernel
+// visits the listed windows and recomputes every output they take part in in the reference's operation order
+// (bit-identical to CTD_NCC_EXACT).
 // One wavefront per listed window, lane <-> disparity; the window itself (FIX, bs x bs) and the rows of
 // the other image it meets over all disparities (SPAN, bs x (bs + D - 1)) are staged in LDS per channel.
 //   frame window  (f, h, w): outputs (f, d, h, w);        SPAN = pattern columns w-half-(D-1) .. w+half
@@ -216,13 +211,10 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
 //                             whole run d' >= d of pixel w = x + d (ext.h:152-154 makes the run constant).
 // The NCC is symmetric in the two windows (dot and sigma0*sigma1 commute exactly), so one staging layout
 // serves both cases.
-constexpr float kPairLimit = 8.f;
-
-__device__ inline float cond_factor(float mean_c, float dev, float n) {
-  if (__float_as_int(dev) < 0) return INFINITY;          // flat window (sign bit set by the pre-pass)
-  const float num = n * mean_c * mean_c, var = dev * dev;
-  return num > 0.f ? 1.f + num / var : 1.f;              // var == 0 with an offset: +inf
-}
+// Ranked calls (ncc_fast_f32 with a RankPlan): every recomputed score outside the runs is also appended to
+// `patches` as (flat pixel index, score) for rank_patch_check_kernel; when the list is full the pixel's dirty byte is
+// set instead (rank_merge_kernel then hands the pixel to the exact re-scoring).  `out` may be null then.
+constexpr int kFixupBlocks = 2048;
 
 // Loops over the window rows stay rolled (a fully unrolled body is ~40 KB of straight-line code that every
 // wavefront executes once -- instruction-fetch bound); BS > 0 unrolls the inner tap loop only.
@@ -232,13 +224,14 @@ __device__ inline float cond_factor(float mean_c, float dev, float n) {
 template <int BS>
 __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         long in1_frame_stride, float* __restrict__ out,
-                                                        const float* __restrict__ m0, const float* __restrict__ v0,
-                                                        const float* __restrict__ m1, const float* __restrict__ v1,
-                                                        long st1_frame_stride, int Wp, int W1, int xoff,
                                                         const unsigned* __restrict__ counters,
                                                         const unsigned long long* __restrict__ list_a,
                                                         const unsigned long long* __restrict__ list_b,
-                                                        float* __restrict__ run_vals, int frames, int C, int H, int W,
+                                                        float* __restrict__ run_vals,
+                                                        unsigned char* __restrict__ dirty,
+                                                        unsigned* __restrict__ n_patches,
+                                                        unsigned long long* __restrict__ patches,
+                                                        unsigned patch_capacity, int frames, int C, int H, int W,
                                                         int D, int bs_rt) {
   extern __shared__ float lds_fix[];
   const int bs = BS > 0 ? BS : bs_rt;
@@ -272,15 +265,8 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
     for (int r = 0; r < rounds; ++r) {
       const int d = r * 64 + lane;
       const int w = is_a ? col : col + d;
-      // is this output out of the fast kernel's accuracy range? (any channel)
-      bool bad = false;
-      if (d < D && w >= 0 && w < W) {
-        for (int c = 0; c < C; ++c) {
-          const long oa = (((long)f * C + c) * H + h) * Wp + w + 4;
-          const long ob = (long)f * st1_frame_stride + ((long)c * H + h) * W1 + (w - d) + xoff;
-          bad = bad | (cond_factor(m0[oa], v0[oa], n) * cond_factor(m1[ob], v1[ob], n) > kPairLimit);
-        }
-      }
+      // every output of a listed window is recomputed (the fast kernels wrote NaN there)
+      const bool bad = d < D && w >= 0 && w < W;
       float val = 0.f;
       if (__any(bad)) {
         for (int c = 0; c < C; ++c) {
@@ -367,7 +353,13 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
       if (run_item) {
         if (d < D) run_vals[((long)f * H + h) * D + d] = bad ? val : __int_as_float(0x7fc00000);
       } else if (bad) {
-        out[((long)f * D + d) * HW + (long)h * W + w] = val;
+        if (out) out[((long)f * D + d) * HW + (long)h * W + w] = val;
+        if (patches) {                                       // the in-kernel ranking left this score out
+          const long pix = ((long)f * H + h) * W + w;
+          const unsigned slot = atomicAdd(n_patches, 1u);
+          if (slot < patch_capacity) patches[slot] = ((unsigned long long)pix << 32) | (unsigned)__float_as_int(val);
+          else dirty[pix] = 1;
+        }
       }
     }
   }
@@ -638,20 +630,12 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
           for (int k = 0; k < BS - 1; ++k) v += P[j][k];
           P[j][u % (BS - 1)] = p;
         }
-#if CTD_ABLATE == 4
-        const float s = v;
-#else
         const float s = lane_window_sum<BS>(v, lane);
-#endif
         const float cov = fmaf(nma, mbv[j], s);
         const float den = fmaf(sav, sbv[j], 1e-8f);
         float val = cov * __builtin_amdgcn_rcpf(den);
         const int d = d_base + j;
-#if CTD_ABLATE == 1
-        if (lane_out && row_out && d < D && val == 123456.789f) {
-#else
         if (lane_out && row_out && d < D) {
-#endif
           const long o = (long)d * HW + (long)h * W + w0;
           if (ACCUM) val += vol[o];
           vol[o] = val;
@@ -676,28 +660,16 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
 // which remains in use for the columns left over when W is not a multiple of 248.
 // ------------------------------------------------------------------------------------
 constexpr int kWCols = 4;                     // product columns per lane
-#ifndef CTD_WND
-#define CTD_WND 2
-#endif
-constexpr int kWND = CTD_WND;                 // disparities per lane (1 or 2)
-#ifndef CTD_WWAVES
-#define CTD_WWAVES 8
-#endif
-#ifndef CTD_WROWS
-#define CTD_WROWS 3
-#endif
-#ifndef CTD_WBUFS
-#define CTD_WBUFS 3
-#endif
-constexpr int kWWaves = CTD_WWAVES;           // consumer wavefronts per workgroup (4 or 8)
+constexpr int kWND = 2;                       // disparities per lane
+constexpr int kWWaves = 8;                    // consumer wavefronts per workgroup
 constexpr int kWDG = kWND * kWWaves;          // disparities per workgroup (8)
 constexpr int kWTile = 64 * kWCols;           // product columns per wavefront (256)
 constexpr int kWOut = 62 * kWCols;            // output columns per wavefront (248)
 constexpr int kWSpan = kWTile + kWDG - 1;     // 263 pattern columns per row
 constexpr int kWSpanPad = (kWSpan + 1 + 3) / 4 * 4;   // multiple of 4, > kWSpan
 constexpr int kWPack = 3 * kWTile + 3 * kWSpanPad;   // 1560 floats per staged row
-constexpr int kWRows = CTD_WROWS;             // rows per LDS chunk
-constexpr int kWBufs = CTD_WBUFS;             // chunks in the ring
+constexpr int kWRows = 3;                     // rows per LDS chunk
+constexpr int kWBufs = 3;                     // chunks in the ring
 constexpr int kWDmaPerRow = 3 + 3 * 2;        // dwordx4 LDS-DMA instructions per row
 
 // Four floats starting OFF slots after the lane's own quad of a 16-byte aligned LDS array:
@@ -797,10 +769,6 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
     lds_read4<0>(pk, lane, o.a);
     lds_read4<0>(pk + kWTile, lane, o.ma);
     lds_read4<0>(pk + 2 * kWTile, lane, o.sa);
-#if CTD_ABLATE2 & 4
-    for (int j = 0; j < kWND; ++j) for (int i = 0; i < 4; ++i) { o.b[j][i] = o.a[i] + j; o.mb[j][i] = o.ma[i]; o.sb[j][i] = o.sa[i]; }
-    return o;
-#endif
     lds_read4<kOff0>(pk + 3 * kWTile, lane, o.b[0]);
     lds_read4<kOff0>(pk + 3 * kWTile + kWSpanPad, lane, o.mb[0]);
     lds_read4<kOff0>(pk + 3 * kWTile + 2 * kWSpanPad, lane, o.sb[0]);
@@ -833,9 +801,6 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
 #pragma unroll
         for (int i = 0; i < kWCols; ++i) {
           const float p = cur.a[i] * cur.b[j][i];
-#if CTD_ABLATE2 & 8
-          x[i] = p + P[j][i][0]; P[j][i][0] = p;
-#else
           if constexpr (BS == 9) {
             const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
             P[j][i][u % 2] = p;
@@ -848,7 +813,6 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
             P[j][i][u % (BS - 1)] = p;
             x[i] = v;
           }
-#endif
         }
         // horizontal window sums of the lane's 4 columns from prefix / suffix sums of the
         // neighbouring lanes: out_i = suffix_prev(i - HALF + 4) + own(i-HALF .. i+TAIL) + prefix_next(i + TAIL - 4)
@@ -862,11 +826,7 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
         float s[kWCols];
         if constexpr (BS == 9) {
           // window = previous lane's columns i..3, all four own columns, next lane's columns 0..i
-#if CTD_ABLATE2 & 1
-          for (int i = 0; i < 4; ++i) s[i] = suf[i] + pre[i];
-#else
           window_combine4(suf, pre[kWCols - 1], pre, s);
-#endif
         } else {
 #pragma unroll
           for (int i = 0; i < kWCols; ++i) {
@@ -885,25 +845,13 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
         float val[kWCols];
 #pragma unroll
         for (int i = 0; i < kWCols; ++i) {
-#if CTD_ABLATE2 & 2
-          val[i] = s[i] + nma[i];
-#else
           const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
           const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
           val[i] = cov * __builtin_amdgcn_rcpf(den);
-#endif
         }
         const int d = d_base + j;
-#if CTD_ABLATE == 1
-        if (row_out && lane_out && d < D && val[0] == 123456.789f) {
-#else
         if (row_out && lane_out && d < D) {
-#endif
-#if CTD_ABLATE == 6
-          float* o = out + ((((long)d * HW + (long)h * W + c0) & 0x3FFFC) | ((long)(blockIdx.x + blockIdx.z) & 7) << 18);
-#else
           float* o = vol + (long)d * HW + (long)h * W + c0;
-#endif
           if constexpr (VEC4) {   // W % 4 == 0 and 16-byte aligned volume: c0 < W implies c0 + 3 < W
             float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
             if (ACCUM) {
@@ -969,9 +917,6 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
     const int sq1 = min(xb + xoff + kWTile + kWCols * lane, W1 - kWCols);     // slots 256.. (first 2 lanes)
     const bool tail_lane = kWTile + kWCols * lane < kWSpan;
     auto issue_chunk = [&](int chunk) {
-#if CTD_ABLATE == 5
-      return;
-#endif
       float* buf = lds + (chunk % kWBufs) * (kWRows * kWPack);
 #pragma unroll
       for (int s = 0; s < kWRows; ++s) {
@@ -1018,10 +963,7 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 #define CTD_WCASE(WV) \
   case WV: wide_consume<BS, ACCUM, VEC4, (WV < kWWaves ? WV : 0)>(lds, out, f, dg, lane, w_lo, c_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
   switch (wave) {
-    CTD_WCASE(0) CTD_WCASE(1) CTD_WCASE(2) CTD_WCASE(3)
-#if CTD_WWAVES > 4
-    CTD_WCASE(4) CTD_WCASE(5) CTD_WCASE(6) CTD_WCASE(7)
-#endif
+    CTD_WCASE(0) CTD_WCASE(1) CTD_WCASE(2) CTD_WCASE(3) CTD_WCASE(4) CTD_WCASE(5) CTD_WCASE(6) CTD_WCASE(7)
     default: break;
   }
 #undef CTD_WCASE
@@ -1039,10 +981,7 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 // (tools/ubench_store.hip), and per-CU operand staging is limited to ~10 B/clk
 // (tools/ubench_struct.hip), hence 16 disparities per workgroup.
 // ------------------------------------------------------------------------------------
-#ifndef CTD_TWAVES
-#define CTD_TWAVES 7
-#endif
-constexpr int kTWaves = CTD_TWAVES;            // consumer wavefronts per workgroup.  7 (+ loader) = two 8-wave workgroups per CU at
+constexpr int kTWaves = 7;                     // consumer wavefronts per workgroup.  7 (+ loader) = two 8-wave workgroups per CU at
                                                // 128 VGPRs = exactly 4 waves on every SIMD; with 6 two SIMDs carry 4 waves and two
                                                // carry 3, and the chunk barrier makes the lighter ones wait (measured: 7 is 9 % faster
                                                // although 10 groups of 14 disparities compute 140 for D = 128)
@@ -1054,22 +993,45 @@ constexpr int kTSpanPad = (kTA + kTDG - 1 + 1 + 3) / 4 * 4;   // multiple of 4, 
 static_assert(kTA + kTDG - 1 < kTSpanPad, "pattern span must fit its padded array");
 constexpr int kTHalo = kTWaves * kTND * 2 * 4; // [wave][j][side][4] halo sums
 constexpr int kTPack = 3 * kTA + 3 * kTSpanPad + kTHalo;   // 1760 floats per staged row
-#ifndef CTD_TROWS
-#define CTD_TROWS 3
-#endif
-#ifndef CTD_TBUFS
-#define CTD_TBUFS 3
-#endif
-constexpr int kTRows = CTD_TROWS;
-constexpr int kTBufs = CTD_TBUFS;
+constexpr int kTRows = 3;
+constexpr int kTBufs = 3;
 constexpr int kTDmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
 constexpr int kTOffB = 3 * kTA, kTOffH = 3 * kTA + 3 * kTSpanPad;
 
-template <bool ACCUM, int WAVE>
-__device__ __forceinline__ void t256_consume(const float* lds, float* __restrict__ out, int f, int dg, int lane,
-                                             int w_lo, int h_lo, int h_hi, int r_begin, int n_iters, int H, int W,
-                                             int D) {
+// ---- in-kernel ranking (MODE & kRank) -------------------------------------------------------------------------
+// The argmax over disparity used to re-read the whole volume (1.8 GB at config 2).  With ranking on, the consumers
+// keep, per output pixel and per workgroup (kTDG disparities), the two largest scores and the disparity of the
+// largest: every score becomes a KEY = the f32 score with its 4 low mantissa bits replaced by 15 - (disparity within
+// the group), so that a plain float maximum carries the index along (relative truncation 2^-19; lower disparity wins
+// among equal truncated positive scores).  Per pixel two LDS slots {top, second} are fed with float atomics:
+//     old = ds_max_rtn_f32(top, hi);  ds_max_f32(second, med3(old, hi, lo))      (hi >= lo: the lane's two keys)
+// -- every key that is not the final maximum is, at some point, the loser of such an exchange, so `second` ends up as
+// the runner-up.  Slots are double-buffered by chunk parity: the rows of chunk k are read out (and reset) by one
+// consumer wavefront per row during chunk k + 1, under the barriers the pipeline already has, and written as two
+// [frames][n_dgroups][H][W] f32 planes (8 B per pixel and group instead of kTDG * 4 B).  rank_merge_kernel
+// (argmax_rerank.hip) merges the groups.  Scores of listed windows are NaN (pre-pass) and never enter: the fix-up
+// pass hands their exact values to the merge (patch list).  Scores past the start of the fully clamped run
+// (ext.h:152-154 makes them copies of its first element) do not take part either; where the run's window is listed
+// its first element is NaN as well and the merge takes the exact run value instead.
+constexpr int kRank = 1, kNoStore = 2;         // MODE bits of the tile-256 kernel
+constexpr int kTRankFloats = 2 * kTRows * 2 * 256;   // [chunk parity][row][top | second][column-in-quad][lane]
+
+__device__ inline float rank_key(float v, int tag) {          // tag = 15 - disparity within the group
+  return __int_as_float((__float_as_int(v) & ~15) | tag);
+}
+__device__ inline float vmaxf_raw(float a, float b) {         // v_max_f32 without the canonicalising self-maxima
+  float r;                                                    // clang adds around llvm.maxnum; a NaN operand loses
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool ACCUM, int MODE, int WAVE>
+__device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0,
+                                             float* __restrict__ rk1, int f, int dg, int lane, int w_lo, int h_lo,
+                                             int h_hi, int r_begin, int n_iters, int H, int W, int D) {
   constexpr int BS = 9, TAIL = 4, STEP = lcm_ce(6, kTRows);
+  constexpr bool RANK = (MODE & kRank) != 0, STORE = (MODE & kNoStore) == 0;
+  static_assert((STEP / kTRows) % 2 == 0, "chunk parity must be a compile-time function of the unrolled row");
   const long HW = (long)H * W;
   const int d_base = dg * kTDG + WAVE * kTND;
   const int c0 = w_lo + 4 * lane;
@@ -1096,6 +1058,54 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
   const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;
   auto quad = [](const float* p) { return *(const f32x4*)p; };
 
+  float* rank_lds = lds - kTRankFloats;                            // in front of the staging ring (see the kernel)
+  // consumer wavefronts that have disparities below D in this group share the read-out of the rank slots
+  const int n_active = min(kTWaves, (D - dg * kTDG + kTND - 1) / kTND);
+  // only the first column tile can reach the fully clamped run (d > w + TAIL needs d_base + 1 > w_lo + TAIL)
+  const bool run_masks = RANK && (d_base + kTND - 1 > w_lo + TAIL);
+  if constexpr (RANK) {
+    if (WAVE == 0) {
+      const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int k = 0; k < kTRankFloats / 256; ++k) *(f32x4*)(rank_lds + 256 * k + 4 * lane) = ninf;
+    }
+  }
+  // rows of chunk `ch` (slot parity `par`) whose read-out falls to this wavefront: slots -> partial planes, reset
+  auto rank_readout = [&](int ch, int par) {
+#pragma unroll
+    for (int s = 0; s < kTRows; ++s) {
+      const int hh = r_begin + ch * kTRows + s - TAIL;
+      if (hh >= h_lo && hh < h_hi && (s + ch) % n_active == WAVE) {      // wave-uniform
+        float* sl = rank_lds + ((par * kTRows + s) * 2) * 256 + lane;
+        f32x4 t, q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { t[i] = sl[64 * i]; q[i] = sl[256 + 64 * i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sl[64 * i] = -INFINITY; sl[256 + 64 * i] = -INFINITY; }
+        if (lane_out) {
+          // uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane 64-bit pointers to keep
+          const unsigned off = (unsigned)(hh * W + c0);
+          __builtin_nontemporal_store(t, (f32x4*)(rk0 + off));
+          __builtin_nontemporal_store(q, (f32x4*)(rk1 + off));
+        }
+      }
+    }
+  };
+  // The runner-up update needs the value the first atomic returns: it is issued at the start of the next row (or at
+  // the chunk barrier), behind that row's operand reads -- LDS answers in order, so the returns are there by the time
+  // the operands are -- instead of being waited for on its own.  Unconditional (a row without outputs leaves -inf
+  // here, a no-op for the maximum): a flag would keep these twelve registers alive across the whole loop.
+  float rk_hi[4], rk_lo[4], rk_old[4];
+  float* rk_sl = rank_lds + lane;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
+  auto rank_second = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      (void)__hip_atomic_fetch_max(rk_sl + 256 + 64 * i, __builtin_amdgcn_fmed3f(rk_old[i], rk_hi[i], rk_lo[i]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
   wg_barrier();                                                    // chunk 0 (operands + halos) is in LDS
   if (d_base >= D) {
     // both disparities of this wavefront lie past D (last disparity group): keep the barrier protocol, skip the work
@@ -1108,14 +1118,28 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
     for (int u = 0; u < STEP; ++u) {
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
-      const float* pk = lds + ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack;
+      const int par = (u / kTRows) & 1;                            // parity of `chunk` (two chunks per iteration)
+      if constexpr (RANK) {
+        if ((u % kTRows) == 0 && chunk > 0) rank_readout(chunk - 1, par ^ 1);
+      }
       // Phase A, every row: products and the vertical 3+3+3 rings of both disparities (needs only the two value
       // quads).  Phase B, output rows only (wave-uniform branch; the (bs-1) warm-up rows of a band skip it):
       // statistics quads requested first so that they arrive under the horizontal sums, then window sums,
       // normalisation and the store.
-      const float* own = pk + 4 * (lane + 1);                      // own quad after the left halo
+      // One per-lane base per row, made opaque: every LDS operand of the row is then base + 16-bit immediate.  (Left
+      // alone the compiler hoists one base VGPR per ring row whose offset does not fit the immediate -- with the
+      // rank slots in front of the ring that is 3 spilled registers, reloaded behind a vmcnt(0) wait every row.)
+      int own_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + 4 * (lane + 1);
+      asm("" : "+v"(own_o));
+      const float* own = lds + own_o;                              // own quad after the left halo
+      int hq_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + kTOffH + halo_side * 4;
+      asm("" : "+v"(hq_o));
+      const float* hqp = lds + hq_o;                               // halo sums of (wave 0, j 0) on this lane's side
       f32x4 qa = quad(own);
-      f32x4 qb0 = quad(pk + kTOffB + 4 * (lane + 1 + kQ)), qb1 = quad(pk + kTOffB + 4 * (lane + 2 + kQ));
+      f32x4 qb0 = quad(own + kTOffB + 4 * kQ), qb1 = quad(own + kTOffB + 4 * (kQ + 1));
+      if constexpr (RANK) {
+        if ((u % kTRows) != 0) rank_second();                      // previous row of this chunk (flushed at the barrier otherwise)
+      }
       asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
       const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
       const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
@@ -1133,10 +1157,16 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
           T[j][i][u % 6] = t3;
         }
       if (row_out) {
+        // is this row's fully clamped run window listed for the fix-up pass (NaN deviation)?  It sits in the staged
+        // pattern-side array at column x = -TAIL, slot dg * kTDG + kTDG - 1 of the first column tile (wave-uniform)
+        int run_listed = 0;
+        if (RANK && run_masks && dg * kTDG + kTDG - 1 < kTSpanPad)
+          run_listed = (__builtin_amdgcn_readfirstlane(__float_as_int(hqp[-kTOffH - halo_side * 4 + kTOffB + 2 * kTSpanPad + dg * kTDG + kTDG - 1])) & 0x7fffffff) > 0x7f800000;
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
-        f32x4 qm0 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 1 + kQ)), qm1 = quad(pk + kTOffB + kTSpanPad + 4 * (lane + 2 + kQ));
-        f32x4 qs0 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 1 + kQ)), qs1 = quad(pk + kTOffB + 2 * kTSpanPad + 4 * (lane + 2 + kQ));
+        f32x4 qm0 = quad(own + kTOffB + kTSpanPad + 4 * kQ), qm1 = quad(own + kTOffB + kTSpanPad + 4 * (kQ + 1));
+        f32x4 qs0 = quad(own + kTOffB + 2 * kTSpanPad + 4 * kQ), qs1 = quad(own + kTOffB + 2 * kTSpanPad + 4 * (kQ + 1));
         float me[8], se[8];
+        float key[kTND][4];
 #pragma unroll
         for (int j = 0; j < kTND; ++j) {
           float pre[4], suf[4];
@@ -1157,7 +1187,7 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
 #pragma unroll
             for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
           }
-          f32x4 hq = quad(pk + kTOffH + ((WAVE * kTND + j) * 2 + halo_side) * 4);
+          f32x4 hq = quad(hqp + (WAVE * kTND + j) * 2 * 4);
           asm("" : "+v"(hq));
           float val[4];
 #pragma unroll
@@ -1168,7 +1198,7 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
             val[i] = cov * __builtin_amdgcn_rcpf(den);
           }
           const int d = d_base + j;
-          if (lane_out && d < D) {
+          if (STORE && lane_out && d < D) {
             float4* o = (float4*)(vol + (long)d * HW + (long)h * W + c0);
             float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
             if (ACCUM) {
@@ -1178,25 +1208,53 @@ __device__ __forceinline__ void t256_consume(const float* lds, float* __restrict
             // written once, next read by another kernel after 1.8 GB more: non-temporal (-8 % on the launch)
             __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, (f32x4*)o);
           }
+          if constexpr (RANK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float k = rank_key(val[i], 15 - (WAVE * kTND + j));
+              if (d >= D) k = -INFINITY;                           // wave-uniform
+              // d > w + TAIL: copy of the run's first element; d == w + TAIL with a listed run window: left to the
+              // merge.  (scalar left-hand side: no per-lane column arithmetic)
+              if (run_masks && d - TAIL - i + run_listed > c0) k = -INFINITY;
+              key[j][i] = k;
+            }
+          }
         }
+        if constexpr (RANK) {
+          rk_sl = rank_lds + ((par * kTRows + (u % kTRows)) * 2) * 256 + lane;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            // NaN keys (scores of listed windows) drop out: v_max returns the other operand, med3 with a NaN its min3
+            rk_hi[i] = vmaxf_raw(key[0][i], key[1][i]);
+            rk_lo[i] = __builtin_amdgcn_fmed3f(key[0][i], key[1][i], -INFINITY);
+            rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      } else if constexpr (RANK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
       }
       if (last_of_chunk) {
+        if constexpr (RANK) rank_second();                         // the slots must be complete at the barrier
         wait_lgkmcnt0();
         wg_barrier();
         ++chunk;
       }
     }
   }
+  if constexpr (RANK) rank_readout(chunk - 1, (chunk - 1) & 1);
 }
 
-template <bool ACCUM>
+template <bool ACCUM, int MODE>
 __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
-    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1,
-    int xoff) {
+    float* __restrict__ out, float* __restrict__ rank0, float* __restrict__ rank1, int C, int c, int H, int W, int D,
+    int band_rows, int n_dgroups, int Wp, int W1, int xoff) {
   constexpr int HALF = 4, TAIL = 4, STEP = lcm_ce(6, kTRows), CPI = STEP / kTRows;   // chunks per outer iteration
-  extern __shared__ float lds[];               // [kTBufs][kTRows][kTPack]
+  // ranking: [kTRankFloats] rank slots first (their addresses then fit the 16-bit DS offset), then the staging ring
+  extern __shared__ float lds_all[];
+  float* lds = lds_all + ((MODE & kRank) ? kTRankFloats : 0);   // [kTBufs][kTRows][kTPack]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
   const int w_lo = blockIdx.x * kTTile;
@@ -1326,13 +1384,13 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     return;
   }
 
+  // partial planes of this (frame, disparity group)
+  float* rk0 = (MODE & kRank) ? rank0 + (long)blockIdx.z * H * W : nullptr;
+  float* rk1 = (MODE & kRank) ? rank1 + (long)blockIdx.z * H * W : nullptr;
 #define CTD_TCASE(WV) \
-  case WV: t256_consume<ACCUM, (WV < kTWaves ? WV : 0)>(lds, out, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+  case WV: t256_consume<ACCUM, MODE, WV>(lds, out, rk0, rk1, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
   switch (wave) {
-    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5)
-#if CTD_TWAVES > 6
-    CTD_TCASE(6) CTD_TCASE(7)
-#endif
+    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5) CTD_TCASE(6)
     default: break;
   }
 #undef CTD_TCASE
@@ -1347,7 +1405,7 @@ struct FastWorkspace {
   unsigned long long *flag_a, *flag_b;
   unsigned long long* run_rows;   // (pattern image << 20 | h) of the listed fully clamped pattern windows
   float* run_vals;            // [frames][H][D] exact values of the fully clamped runs (ncc_fixup_runs_kernel)
-  size_t bytes;
+  size_t bytes;               // end of the volume pass's own workspace; the ranking buffers (RankPlan) follow
 };
 
 static FastWorkspace fast_workspace(void* base, int frames, int C, int H, int W, int D, bool per_frame_pattern) {
@@ -1386,6 +1444,46 @@ size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, 
   return fast_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
 }
 
+bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs) {
+  (void)H;
+  return C == 1 && bs == 9 && W % 4 == 0 && D <= 512;      // the tile-256 kernel, single channel
+}
+
+// ranking buffers behind the volume pass's workspace
+static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, int D) {
+  RankPlan rp;
+  rp.n_dg = ceil_div(D, kTDG);
+  rp.dg_size = kTDG;
+  const size_t npart = align_up((size_t)frames * rp.n_dg * H * W * sizeof(float), 256);
+  const size_t ndirty = align_up((size_t)frames * H * W, 256);
+  const size_t nlist = align_up((size_t)frames * H * W * sizeof(int64_t), 256);
+  char* p = (char*)base + offset;
+  rp.k0 = (float*)p;
+  rp.k1 = (float*)(p + npart);
+  rp.dirty = (unsigned char*)(p + 2 * npart);
+  rp.n_hard = (unsigned*)(p + 2 * npart + ndirty);
+  rp.hard_list = (int64_t*)(p + 2 * npart + ndirty + 256);
+  rp.patches = (const unsigned long long*)(p + 2 * npart + ndirty + 256 + nlist);
+  rp.patch_capacity = (unsigned)((size_t)frames * H * W);
+  rp.n_patches = nullptr;
+  rp.best_scratch = (float*)(p + 2 * npart + ndirty + 256 + 2 * nlist);
+  rp.bytes = offset + 2 * npart + ndirty + 256 + 2 * nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
+  rp.run_flag = nullptr; rp.run_flag_frame_stride = 0; rp.run_flag_row_stride = 0; rp.run_vals = nullptr;
+  return rp;
+}
+
+void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off) {
+  const size_t base = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern).bytes;
+  const RankPlan rp = rank_plan(nullptr, base, frames, H, W, D);
+  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.k1; off[2] = (size_t)rp.dirty; off[3] = (size_t)rp.n_hard;
+  off[4] = (size_t)rp.hard_list; off[5] = (size_t)rp.n_dg;
+}
+
+size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern) {
+  const size_t off = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern).bytes;
+  return rank_plan(nullptr, off, frames, H, W, D).bytes;
+}
+
 static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int W, int bs, hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
@@ -1407,9 +1505,10 @@ static int pick_bands(long wg_per_band, int H, int bs) {
 
 template <int BS>
 static int launch_fast(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
-                       int W, int D, const FastWorkspace& ws, hipStream_t stream) {
+                       int W, int D, const FastWorkspace& ws, const RankPlan* rank, hipStream_t stream) {
   constexpr int WOUT = 64 - (BS - 1);
   const long st1_stride = in1_frame_stride ? (long)C * H * ws.W1 : 0;
+  if (rank && !(BS == 9 && W % 4 == 0 && C == 1 && ((uintptr_t)out) % 16 == 0)) return CTD_ERR_UNSUPPORTED;
   if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0) {
     // production path: 256-column tiles, every store a full aligned KB
     const int n_dg = ceil_div(D, kTDG);
@@ -1420,14 +1519,16 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     const int bands = H >= 66 ? (H + 22) / 44 : 1;
     const int band_rows = ceil_div(H, bands);
     dim3 grid(n_tiles, ceil_div(H, band_rows), frames * n_dg), block(64 * (kTWaves + 1));
-    const size_t lds = sizeof(float) * kTBufs * kTRows * kTPack;
+    const size_t lds = sizeof(float) * (kTBufs * kTRows * kTPack + (rank ? kTRankFloats : 0));
     for (int c = 0; c < C; ++c) {
-      auto kern = c == 0 ? ncc_fast_t256_kernel<false> : ncc_fast_t256_kernel<true>;
+      auto kern = c == 0 ? ncc_fast_t256_kernel<false, 0> : ncc_fast_t256_kernel<true, 0>;
+      if (rank) kern = out ? ncc_fast_t256_kernel<false, kRank> : ncc_fast_t256_kernel<false, kRank | kNoStore>;
       if (lds > 64 * 1024)
         CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       timing_begin(stream);
-      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C,
-                         c, H, W, D, band_rows, n_dg, ws.Wp, ws.W1, ws.xoff);
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
+                         rank ? rank->k0 : nullptr, rank ? rank->k1 : nullptr, C, c, H, W, D, band_rows, n_dg, ws.Wp,
+                         ws.W1, ws.xoff);
       timing_end(stream, W);
       CTD_LAUNCH_CHECK();
     }
@@ -1475,28 +1576,42 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
   return CTD_OK;
 }
 
+// `rank` non-null: also rank every pixel's scores inside the volume kernel (see t256_consume) and fill *rank with
+// the buffers rank_merge_f32 (argmax_rerank.hip) needs; `out` may then be null (no volume is materialised).
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
-                 int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
   if (H >= (1 << 20) || W + D >= (1 << 19) || D > 512 || (long)frames * C >= (1 << 24)) return CTD_ERR_UNSUPPORTED;
+  if (!out && !rank) return CTD_ERR_INVALID_ARG;
+  if (rank && !ncc_fast_rank_supported(C, H, W, D, bs)) return CTD_ERR_UNSUPPORTED;
   const bool per_frame = in1_frame_stride != 0;
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
-  if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
+  size_t need = ws.bytes;
+  if (rank) {
+    *rank = rank_plan(workspace, ws.bytes, frames, H, W, D);
+    need = rank->bytes;
+    rank->run_flag = ws.v1 + (-(bs - 1 - bs / 2) + ws.xoff);     // deviation plane at the run window's column
+    rank->run_flag_frame_stride = per_frame ? (long)C * H * ws.W1 : 0;
+    rank->run_flag_row_stride = ws.W1;
+    rank->run_vals = ws.run_vals;
+    rank->n_patches = ws.counters + 3;                           // cleared with the other counters below
+  }
+  if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
   // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr};
+                         nullptr, nullptr, rank ? rank->dirty : nullptr};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows};
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, nullptr};
   int st = launch_prepass(ja, jb, H, W, bs, stream);
   if (st) return st;
   switch (bs) {
-    case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
-    case 5: st = launch_fast<5>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
-    case 7: st = launch_fast<7>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
-    case 9: st = launch_fast<9>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, stream); break;
+    case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;
+    case 5: st = launch_fast<5>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;
+    case 7: st = launch_fast<7>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;
+    case 9: st = launch_fast<9>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;
     default: return CTD_ERR_UNSUPPORTED;
   }
   if (st) return st;
@@ -1507,14 +1622,22 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   auto fix = bs == 9 ? ncc_fixup_kernel<9> : ncc_fixup_kernel<0>;
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(fix, dim3(CTD_FIXUP_BLOCKS), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.m0, ws.v0, ws.m1, ws.v1,
-                     per_frame ? (long)C * H * ws.W1 : 0L, ws.Wp, ws.W1, ws.xoff, ws.counters, ws.flag_a, ws.flag_b,
-                     ws.run_vals, frames, C, H, W, D, bs);
+  hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
+                     ws.flag_a, ws.flag_b, ws.run_vals, rank ? rank->dirty : nullptr, rank ? ws.counters + 3 : nullptr,
+                     rank ? (unsigned long long*)rank->patches : nullptr, rank ? rank->patch_capacity : 0u, frames, C, H, W,
+                     D, bs);
   CTD_LAUNCH_CHECK();
+  // the work-list counter of the ranking pass that follows is cleared by the runs kernel (no memset of its own):
+  // the old scan keeps it at the start of the workspace, which the volume kernel is done with by now
+  unsigned* counter = rank ? rank->n_hard : (unsigned*)workspace;
+  if (!out) {                                                // nothing to spread without a volume
+    CTD_HIP_TRY(hipMemsetAsync(counter, 0, 16, stream));
+    return CTD_OK;
+  }
   const size_t lds_rows = sizeof(int) * (size_t)C * H;
   if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
-                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, (unsigned*)workspace);
+                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, counter);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

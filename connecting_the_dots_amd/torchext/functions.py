@@ -238,8 +238,10 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
     a = _ALGOS[algo or _default_algo()]
     idx = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     best = torch.empty((N, H, W), dtype=torch.float32, device=dev)
-    vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if (return_volume or a == 1) else None
-    ws = _workspace(L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a), dev)
+    # the fast path ranks inside the volume kernel where it can (no volume needed); other shapes rank a materialised one
+    need_vol = a == 1 and not L.ctd_xcorrvol_rank_supported(C, H, W, D, bs)
+    vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if (return_volume or need_vol) else None
+    ws = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, bs, a), dev)
     st = L.ctd_xcorrvol_argmax_f32(_ptr(a0), _ptr(in1), stride1, _ptr(vol), _ptr(idx), _ptr(best), N, C, H, W, D, bs,
                                    a, float(rerank_eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
     _lib.check(st, "xcorrvol_argmax")

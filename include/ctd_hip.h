@@ -102,11 +102,23 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
  * CTD_NCC_EXACT: fused, vol_out may be NULL (no volume written) or [frames][D][H][W]
  *   (written as well); indices equal torch.argmax(xcorrvol_cpu(...), 0) bit for bit and
  *   best is the reference-order score.
- * CTD_NCC_FAST: vol_out is required (the fast volume is materialised, then ranked in one
- *   pass); every disparity whose fast score lies within `rerank_eps` of the pixel's best
- *   is re-scored in reference order, so the indices are those of the reference-order
- *   volume whenever |fast - exact| <= rerank_eps / 2; best = vol_out[idx].
+ * CTD_NCC_FAST: every disparity whose fast score lies within `rerank_eps` of the pixel's
+ *   best is re-scored in reference order, so the indices are those of the reference-order
+ *   volume whenever |fast - exact| <= rerank_eps / 2 (rerank_eps < 0: plain argmax of the
+ *   fast scores).  Where ctd_xcorrvol_rank_supported() holds (block 9, W % 4 == 0) the
+ *   volume kernel ranks the scores itself (per-group top-2 partials, no second pass over
+ *   the volume) and vol_out may be NULL: nothing is materialised then.  Otherwise vol_out
+ *   is required (CTD_ERR_INVALID_ARG if NULL) and ranked in one more pass.  best = the
+ *   fast score of idx, within 2^-20 relative of vol_out[idx] (the reference-order score
+ *   for re-scored pixels when no volume is written).
+ * Workspace: ctd_xcorrvol_argmax_workspace_bytes().
  * -------------------------------------------------------------------------------------- */
+int ctd_xcorrvol_rank_supported(int C, int H, int W, int D, int block_size);
+/* Inspection aid for tests / tools: byte offsets, inside the workspace of a ranked ctd_xcorrvol_argmax_f32 call, of
+ * offsets[0..4] = top-key planes, second-key planes ([frames][groups][H][W] f32 each), dirty bytes [frames][H][W],
+ * the work-list counter (u32) and the work list (i64 flat pixel indices); offsets[5] = number of disparity groups. */
+int ctd_xcorrvol_rank_layout(int frames, int H, int W, int D, int per_frame_pattern, size_t* offsets);
+size_t ctd_xcorrvol_argmax_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo);
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,
                             float* vol_out, int64_t* idx, float* best, int frames, int C, int H,
                             int W, int D, int block_size, int algo, float rerank_eps,

@@ -1,0 +1,146 @@
+"""GPU parity of the in-kernel ranking of the fast NCC path (ncc_fast.hip t256_consume -> rank_merge_kernel ->
+argmax_resolve_kernel): indices must equal torch.argmax of the reference-order volume bit for bit, with the volume
+materialised (return_volume=True) and without one (volume-free).  The checker is the reference-order HIP kernel
+(`algo='exact'`), itself pinned bit for bit to the reference's goldens in test_xcorrvol_gpu.py, and the CPU oracle
+for the small cases."""
+import numpy as np
+import pytest
+import torch
+
+from tests import workloads
+from tests.util import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def te():
+    from connecting_the_dots_amd import torchext
+    return torchext
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def check_both_modes(te, A, B, D, what, exact=None):
+    """fast + rank (with and without a volume) vs the reference-order kernel"""
+    if exact is None:
+        exact = te.xcorrvol_argmax(A, B, D, 9, return_volume=True, algo="exact")
+    idx_e, best_e, vol_e = exact
+    idx_v, best_v, vol_v = te.xcorrvol_argmax(A, B, D, 9, return_volume=True, algo="fast")
+    idx_n, best_n = te.xcorrvol_argmax(A, B, D, 9, algo="fast")
+    bad_v, bad_n = int((idx_v != idx_e).sum()), int((idx_n != idx_e).sum())
+    assert bad_v == 0 and bad_n == 0, "%s: %d / %d of %d indices differ (volume / volume-free)" % (
+        what, bad_v, bad_n, idx_e.numel())
+    # the materialised volume is the plain fast volume (ranking must not disturb it)
+    plain = te.xcorrvol_batch(A if A.dim() == 4 else A[None], B, D, 9, algo="fast")
+    assert torch.equal(vol_v if vol_v.dim() == 4 else vol_v[None], plain), what
+    tol = vol_e.abs().amax(-3) * 1e-5 + 2e-6          # fast score + key truncation (2^-20 relative)
+    assert bool(((best_v - best_e).abs() <= tol).all()), what
+    assert bool(((best_n - best_e).abs() <= tol).all()), what
+    return idx_e
+
+
+@pytest.mark.parametrize("N,H,W,D", [(1, 9, 4, 1), (1, 3, 8, 2), (2, 20, 64, 13), (1, 31, 256, 14), (1, 17, 260, 15),
+                                     (3, 45, 300, 27), (1, 50, 512, 28), (1, 12, 516, 129), (2, 67, 128, 130),
+                                     (1, 10, 1024, 256), (1, 6, 72, 300)])
+def test_rank_shapes(te, N, H, W, D):
+    rs = np.random.RandomState(N * 1000 + H + W + D)
+    A = dev(rs.randn(N, 1, H, W).astype(np.float32))
+    B = dev(rs.randn(1, H, W).astype(np.float32))
+    check_both_modes(te, A, B, D, (N, H, W, D))
+
+
+def test_rank_small_goldens_vs_reference(te):
+    """indices of the reference itself (ext_cpu goldens), through both rank modes"""
+    g = golden("xcorrvol_small")
+    n = 0
+    for k, (C, H, W, D, bs) in enumerate(g["cases"]):
+        if C != 1 or g["in0_%d" % k].dtype != np.float32 or bs != 9 or W % 4:
+            continue
+        n += 1
+        A, B = dev(g["in0_%d" % k]), dev(g["in1_%d" % k])
+        for rv in (False, True):
+            out = te.xcorrvol_argmax(A, B, int(D), 9, return_volume=rv, algo="fast")
+            assert np.array_equal(out[0].cpu().numpy(), g["argmax_%d" % k]), (k, rv)
+            assert_close(out[1].cpu().numpy(), g["vol_%d" % k].max(0), atol=2e-6, what="best %d" % k)
+    assert n >= 1
+
+
+def test_rank_per_frame_pattern_and_dots(te):
+    rs = np.random.RandomState(5)
+    N, H, W, D = 3, 40, 128, 64
+    a = rs.randn(N, 1, H, W).astype(np.float32)
+    b = (rs.rand(N, 1, H, W) < 0.1).astype(np.float32)       # raw dot patterns: many flat windows, exact ties
+    check_both_modes(te, dev(a), dev(b), D, "per-frame dots")
+    check_both_modes(te, dev(a), dev(b[0]), D, "shared dots")
+
+
+def test_rank_listed_runs_and_flat_blocks(te, oracle):
+    """flat left border (listed fully clamped run), flat interior blocks on both sides, DC offset: the ranking sees
+    unpatched scores there; dirty pixels and the run candidate must bring the reference's indices back"""
+    rs = np.random.RandomState(23)
+    N, H, W, D = 2, 40, 96, 40
+    yy, xx = np.mgrid[0:H, 0:W]
+    bg = (100 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.float32)
+    a = (rs.rand(N, 1, H, W) * 8 + bg).astype(np.float32)
+    a[:, :, 5:22, 30:60] = 0.25
+    b = (rs.rand(1, H, W) * 20 + 0.6 * bg).astype(np.float32)
+    b[:, 10:30, 0:3] = 7.0
+    b[:, 24:38, 50:70] = 0.0
+    idx_e = check_both_modes(te, dev(a), dev(b), D, "listed")
+    ref = np.stack([oracle.xcorrvol(a[f], b, D, 9, nthreads=8) for f in range(N)])
+    assert np.array_equal(idx_e.cpu().numpy(), ref.argmax(1))
+
+
+def test_rank_constant_and_periodic(te):
+    a = np.full((1, 1, 24, 64), 0.5, np.float32)
+    b = np.full((1, 24, 64), 0.25, np.float32)
+    b[0, 10, 20] = 1.0
+    check_both_modes(te, dev(a), dev(b), 16, "constant")
+    # period-8 stripes: exact ties between disparities 8 apart everywhere (first index must win)
+    xx = np.arange(128, dtype=np.float32)
+    s = np.sin(2 * np.pi * xx / 8)[None, None, :].repeat(30, 1).astype(np.float32)
+    n = np.random.RandomState(1).randn(1, 30, 128).astype(np.float32) * 1e-3
+    check_both_modes(te, dev((s + n)[None]), dev(s + n), 40, "periodic")
+    check_both_modes(te, dev(s[None]), dev(s), 40, "periodic exact")
+
+
+def test_rank_synthetic_dot_pattern_lcn(te):
+    """the bench workload at reduced height: LCN'd uniform frames against the LCN'd seeded dot pattern (flat
+    column-0 windows -> listed runs in a third of the rows)"""
+    H, W, D = 96, 512, 128
+    fr = np.stack([workloads.uniform_frame(1234 + i, H, W) for i in range(2)])
+    pat = workloads.syn_dot_pattern(H, W, seed=42)[None, None]
+    x, _ = te.lcn(dev(fr), 5, 0.05)
+    p, _ = te.lcn(dev(pat), 5, 0.05)
+    check_both_modes(te, x, p[0].contiguous(), D, "dot pattern")
+
+
+def test_rank_full_size_goldens(te, oracle):
+    """BASELINE config 1/2 shape: disparity MAE vs the reference == 0 on both golden workloads, both modes"""
+    g = golden("xcorrvol_cfg1")
+    a = workloads.uniform_frame(1234, 432, 512)
+    b = workloads.uniform_frame(42, 432, 512)
+    for rv in (False, True):
+        idx = te.xcorrvol_argmax(dev(a), dev(b), 128, 9, return_volume=rv, algo="fast")[0]
+        assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["uni_argmax"]), rv
+    pat = g["kin_pattern_u8"].astype(np.float32) / 255
+    ir, _ = workloads.synth_ir(pat, np.random.RandomState(2024), 128)
+    ir_l, _ = oracle.lcn(ir[None, None], 5, 0.05)
+    pat_l, _ = oracle.lcn(pat[None, None], 5, 0.05)
+    for rv in (False, True):
+        idx = te.xcorrvol_argmax(dev(ir_l[0]), dev(pat_l[0]), 128, 9, return_volume=rv, algo="fast")[0]
+        assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["kin_argmax"]), rv
+
+
+def test_rank_eps_negative_is_plain_fast_argmax(te):
+    """rerank_eps < 0: no re-scoring; the key-ranked index must then hold a score within the key truncation of the
+    fast volume's maximum"""
+    rs = np.random.RandomState(9)
+    A, B = dev(rs.randn(2, 1, 30, 256).astype(np.float32)), dev(rs.randn(1, 30, 256).astype(np.float32))
+    idx, best, vol = te.xcorrvol_argmax(A, B, 64, 9, return_volume=True, algo="fast", rerank_eps=-1.0)
+    picked = vol.gather(1, idx[:, None])[:, 0]
+    # scores of the clamped run are copies: compare values, not indices
+    assert bool((vol.amax(1) - picked <= vol.amax(1).abs() * 4e-6 + 1e-7).all())
