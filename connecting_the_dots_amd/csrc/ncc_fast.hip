@@ -1034,9 +1034,11 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
   static_assert((STEP / kTRows) % 2 == 0, "chunk parity must be a compile-time function of the unrolled row");
   const long HW = (long)H * W;
   const int d_base = dg * kTDG + WAVE * kTND;
-  const int c0 = w_lo + 4 * lane;
-  float* vol = out + (long)f * D * HW;
-  const bool lane_out = c0 < W;
+  // per-lane column arithmetic is kept to ONE register, 4 * lane: everything else about the column tile (w_lo) goes
+  // into scalar bases -- the consumers run at the 128-VGPR limit of four wavefronts per SIMD
+  const unsigned l4 = 4u * (unsigned)lane;                         // first column of the lane, relative to w_lo
+  float* vol = out + (long)f * D * HW + w_lo;
+  const bool lane_out = w_lo + (int)l4 < W;
   const float nf = (float)(BS * BS);
   float P[kTND][4][2], T[kTND][4][6];
 #pragma unroll
@@ -1084,9 +1086,8 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         for (int i = 0; i < 4; ++i) { sl[64 * i] = -INFINITY; sl[256 + 64 * i] = -INFINITY; }
         if (lane_out) {
           // uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane 64-bit pointers to keep
-          const unsigned off = (unsigned)(hh * W + c0);
-          __builtin_nontemporal_store(t, (f32x4*)(rk0 + off));
-          __builtin_nontemporal_store(q, (f32x4*)(rk1 + off));
+          __builtin_nontemporal_store(t, (f32x4*)(rk0 + ((long)hh * W + w_lo) + l4));
+          __builtin_nontemporal_store(q, (f32x4*)(rk1 + ((long)hh * W + w_lo) + l4));
         }
       }
     }
@@ -1161,7 +1162,9 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         // pattern-side array at column x = -TAIL, slot dg * kTDG + kTDG - 1 of the first column tile (wave-uniform)
         int run_listed = 0;
         if (RANK && run_masks && dg * kTDG + kTDG - 1 < kTSpanPad)
-          run_listed = (__builtin_amdgcn_readfirstlane(__float_as_int(hqp[-kTOffH - halo_side * 4 + kTOffB + 2 * kTSpanPad + dg * kTDG + kTDG - 1])) & 0x7fffffff) > 0x7f800000;
+          run_listed = (__builtin_amdgcn_readfirstlane(__float_as_int(
+                            lds[((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + kTOffB + 2 * kTSpanPad + dg * kTDG + kTDG - 1])) &
+                        0x7fffffff) > 0x7f800000;                  // uniform address: no per-lane register to keep
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
         f32x4 qm0 = quad(own + kTOffB + kTSpanPad + 4 * kQ), qm1 = quad(own + kTOffB + kTSpanPad + 4 * (kQ + 1));
         f32x4 qs0 = quad(own + kTOffB + 2 * kTSpanPad + 4 * kQ), qs1 = quad(own + kTOffB + 2 * kTSpanPad + 4 * (kQ + 1));
@@ -1199,7 +1202,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           }
           const int d = d_base + j;
           if (STORE && lane_out && d < D) {
-            float4* o = (float4*)(vol + (long)d * HW + (long)h * W + c0);
+            float4* o = (float4*)(vol + ((long)d * HW + (long)h * W) + l4);
             float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
             if (ACCUM) {
               const float4 old = *o;
@@ -1215,7 +1218,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
               if (d >= D) k = -INFINITY;                           // wave-uniform
               // d > w + TAIL: copy of the run's first element; d == w + TAIL with a listed run window: left to the
               // merge.  (scalar left-hand side: no per-lane column arithmetic)
-              if (run_masks && d - TAIL - i + run_listed > c0) k = -INFINITY;
+              if (run_masks && d - TAIL - i + run_listed - w_lo > (int)l4) k = -INFINITY;
               key[j][i] = k;
             }
           }
