@@ -96,14 +96,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 }
 
 // Merge of the per-group partials written by the volume kernel's in-kernel ranking (ncc_fast.hip, t256_consume):
-// 4 adjacent pixels per thread, two 16-byte loads per disparity group.  Keys are scores whose 4 low mantissa bits hold
-// 15 - (disparity within the group), so the maximum carries its index; a listed fully clamped run contributes its exact
-// value (run_vals) as one more candidate at its first disparity.  A pixel whose runner-up lies within eps (+ the key
-// truncation) of its best goes to the resolve pass (work list); so does one whose patched scores did not fit the
-// patch list (dirty byte set by the fix-up pass).  The dirty bytes are rewritten as "is on the work list" flags for
-// rank_patch_check_kernel.
-__global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
-                                                         int n_dg, int dg_size, const float* __restrict__ run_flag,
+// 4 adjacent pixels per thread, one 16-byte load per disparity group.  A partial is the group's top score with
+// mantissa bits 0-3 = 15 - (disparity within the group) -- so the maximum carries its index -- and bit 4 = "the
+// group's runner-up lies within the re-ranking margin of its top".  A listed fully clamped run contributes its exact
+// value (run_vals) as one more candidate at its first disparity.  A pixel whose runner-up (another group's top, the
+// flagged in-group one, the run value) lies within the margin of its best goes to the resolve pass (work list); so
+// does one whose patched scores did not fit the patch list (dirty byte set by the fix-up pass).  The dirty bytes are
+// rewritten as "is on the work list" flags for rank_patch_check_kernel.
+__device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }   // as in ncc_fast.hip
+
+__global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, int n_dg, int dg_size,
+                                                         const float* __restrict__ run_flag,
                                                          long run_flag_frame_stride, long run_flag_row_stride,
                                                          const float* __restrict__ run_vals,
                                                          unsigned char* __restrict__ dirty,
@@ -118,28 +121,22 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
   const long f = p0 / HW, q0 = p0 - f * HW;
   const int h = (int)(q0 / W), w0 = (int)(q0 - (long)h * W);
   const float* a0 = k0 + f * n_dg * HW + q0;
-  const float* a1 = k1 + f * n_dg * HW + q0;
   float M[4], R[4];
   int gi[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { M[k] = -INFINITY; R[k] = -INFINITY; gi[k] = 0; }
-  constexpr int kB = 5;                                       // groups per batch of independent loads
+  constexpr int kB = 10;                                      // groups per batch of independent loads
   for (int g0 = 0; g0 < n_dg; g0 += kB) {
-    f4 x0[kB], x1[kB];
+    f4 x0[kB];
 #pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const long o = (long)min(g0 + u, n_dg - 1) * HW;
-      x0[u] = __builtin_nontemporal_load((const f4*)(a0 + o));
-      x1[u] = __builtin_nontemporal_load((const f4*)(a1 + o));
-    }
+    for (int u = 0; u < kB; ++u) x0[u] = __builtin_nontemporal_load((const f4*)(a0 + (long)min(g0 + u, n_dg - 1) * HW));
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       if (g0 + u >= n_dg) break;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float top = x0[u][k], sec = x1[u][k];
-        // runner-up of the union of {M >= R} and {top >= sec}
-        R[k] = fmaxf(fmaxf(fminf(M[k], top), R[k]), sec);
+        const float top = x0[u][k];
+        R[k] = __builtin_amdgcn_fmed3f(M[k], R[k], top);        // second largest of the tops
         gi[k] = top > M[k] ? g0 + u : gi[k];                    // strict >: the lower group keeps a tie
         M[k] = fmaxf(M[k], top);
       }
@@ -154,18 +151,19 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
   for (int k = 0; k < 4; ++k) {
     const int w = w0 + k;
     int d = gi[k] * dg_size + 15 - (__float_as_int(M[k]) & 15);
-    float b = __int_as_float((__float_as_int(M[k]) & ~15) | 8);  // centre of the truncation interval
+    float b = __int_as_float((__float_as_int(M[k]) & ~31) | 16);  // centre of the truncation interval
     float m = M[k], r = R[k];
+    bool close = (__float_as_int(M[k]) & 16) != 0;              // in-group runner-up within the margin (volume kernel)
     if (run_listed && w + tail < D) {
       const float c = run_vals[(f * H + h) * D + w + tail];
       if (c == c) {                                             // not NaN: the run's exact score competes at its first disparity
-        if (c > m) { r = m; m = c; b = c; d = w + tail; }
+        if (c > m) { r = m; m = c; b = c; d = w + tail; close = false; }
         else r = fmaxf(r, c);
       }
     }
-    const float margin = eps + 4e-6f * fmaxf(1.f, fabsf(m));    // two keys, each truncated by <= 2^-19 relative
     // m == -inf: every score of the pixel was left to the fix-up pass
-    const bool hard = eps >= 0.f && (((dirty4 >> (8 * k)) & 0xff) != 0 || r >= m - margin || !(m > -INFINITY));
+    const bool hard = eps >= 0.f && (((dirty4 >> (8 * k)) & 0xff) != 0 || close || r >= m - rank_margin(eps, m) ||
+                                     !(m > -INFINITY));
     idx[p0 + k] = d;
     bq[k] = b;
     if (hard) {
@@ -190,8 +188,7 @@ __global__ __launch_bounds__(256) void rank_patch_check_kernel(const unsigned* _
     const unsigned long long e = patches[i];
     const unsigned pix = (unsigned)(e >> 32);
     const float val = __int_as_float((int)(unsigned)e), m = best[pix];
-    const float margin = eps + 4e-6f * fmaxf(1.f, fabsf(m));
-    if (!(val < m - margin)) {                                 // also NaN
+    if (!(val < m - rank_margin(eps, m))) {                   // also NaN
       const unsigned bit = 1u << (8 * (pix & 3));
       if ((atomicOr(flags + (pix >> 2), bit) & bit) == 0) hard_list[atomicAdd(n_hard, 1u)] = pix;
     }
@@ -366,7 +363,7 @@ int rank_merge_f32(const RankPlan& rp, const float* vol, const float* in0, const
   if (D > kMaskWords * 64 || W % 4 != 0) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
   float* scratch_best = best ? best : rp.best_scratch;
-  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0, rp.k1,
+  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0,
                      rp.n_dg, rp.dg_size, rp.run_flag, rp.run_flag_frame_stride, rp.run_flag_row_stride, rp.run_vals,
                      rp.dirty, idx, scratch_best, D, H, W, bs - 1 - bs / 2, eps, total / 4, rp.n_hard, rp.hard_list);
   CTD_LAUNCH_CHECK();

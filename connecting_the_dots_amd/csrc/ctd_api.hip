@@ -157,6 +157,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     if (ncc_fast_rank_supported(1, H, W, D, block_size) && ((uintptr_t)vol_out) % 16 == 0) {
       // ranked inside the volume kernel: partial top-2 per disparity group, merged here; no pass over the volume
       RankPlan rp;
+      rp.eps = rerank_eps;
       int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
                             workspace_bytes, &rp, (hipStream_t)stream);
       if (st) return st;

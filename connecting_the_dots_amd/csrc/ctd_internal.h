@@ -23,8 +23,10 @@ int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int
 // ncc_fast.hip
 // Buffers of the in-kernel ranking (all inside the caller's workspace, laid out by ncc_fast_f32).
 struct RankPlan {
-  float *k0, *k1;             // [frames][n_dg][H][W] largest / second largest score KEY of every disparity group
-  int n_dg, dg_size;          // disparity groups, disparities per group; key = score with low 4 mantissa bits = 15 - d % dg_size
+  float eps;                  // in: re-ranking margin requested by the caller (< 0: none)
+  float* k0;                  // [frames][n_dg][H][W] top score KEY of every disparity group: the f32 score with mantissa
+                              // bits 0-3 = 15 - d % dg_size and bit 4 = "group's runner-up within the margin of its top"
+  int n_dg, dg_size;          // disparity groups, disparities per group
   unsigned char* dirty;       // [frames][H][W] in: 1 = a patched score of this pixel did not fit the patch list;
                               // out (rank_merge_kernel): 1 = pixel is on the work list
   const unsigned* n_patches;  // scores recomputed by the fix-up pass outside the runs: (flat pixel << 32 | f32 bits)

@@ -1006,15 +1006,23 @@ constexpr int kTOffB = 3 * kTA, kTOffH = 3 * kTA + 3 * kTSpanPad;
 // among equal truncated positive scores).  Per pixel two LDS slots {top, second} are fed with float atomics:
 //     old = ds_max_rtn_f32(top, hi);  ds_max_f32(second, med3(old, hi, lo))      (hi >= lo: the lane's two keys)
 // -- every key that is not the final maximum is, at some point, the loser of such an exchange, so `second` ends up as
-// the runner-up.  Slots are double-buffered by chunk parity: the rows of chunk k are read out (and reset) by one
-// consumer wavefront per row during chunk k + 1, under the barriers the pipeline already has, and written as two
-// [frames][n_dgroups][H][W] f32 planes (8 B per pixel and group instead of kTDG * 4 B).  rank_merge_kernel
-// (argmax_rerank.hip) merges the groups.  Scores of listed windows are NaN (pre-pass) and never enter: the fix-up
-// pass hands their exact values to the merge (patch list).  Scores past the start of the fully clamped run
-// (ext.h:152-154 makes them copies of its first element) do not take part either; where the run's window is listed
-// its first element is NaN as well and the merge takes the exact run value instead.
+// the runner-up.  The second atomic of a row is issued at the start of the next row (its operand is the first one's
+// return value).  Slots form a ring of three chunks: the rows of chunk k are complete at the barrier that ends chunk
+// k + 1 and are read out (and reset) by one consumer wavefront per row during chunk k + 2, under the barriers the
+// pipeline already has.  What leaves the kernel is ONE f32 word per pixel and group, [frames][n_dgroups][H][W]
+// (4 B instead of kTDG * 4 B): the top key with mantissa bit 4 replaced by "the group's runner-up lies within the
+// re-ranking margin of its top" -- all the merge needs to know about it.  rank_merge_kernel (argmax_rerank.hip)
+// merges the groups.  Scores of listed windows are NaN (pre-pass) and never enter: the fix-up pass hands their exact
+// values to the merge (patch list).  Scores past the start of the fully clamped run (ext.h:152-154 makes them copies
+// of its first element) do not take part either; where the run's window is listed its first element is NaN like any
+// listed score and the merge takes the exact run value instead.
 constexpr int kRank = 1, kNoStore = 2;         // MODE bits of the tile-256 kernel
-constexpr int kTRankFloats = 2 * kTRows * 2 * 256;   // [chunk parity][row][top | second][column-in-quad][lane]
+constexpr int kTRankBufs = 3;
+constexpr int kTRankFloats = kTRankBufs * kTRows * 2 * 256;   // [chunk % 3][row][top | second][column-in-quad][lane]
+
+// margin inside which two scores count as tied for the exact re-scoring: the caller's eps plus the truncation of two
+// keys (5 mantissa bits each: tag + flag); the same expression in the volume kernel and in rank_merge_kernel
+__device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }
 
 __device__ inline float rank_key(float v, int tag) {          // tag = 15 - disparity within the group
   return __int_as_float((__float_as_int(v) & ~15) | tag);
@@ -1026,12 +1034,11 @@ __device__ inline float vmaxf_raw(float a, float b) {         // v_max_f32 witho
 }
 
 template <bool ACCUM, int MODE, int WAVE>
-__device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0,
-                                             float* __restrict__ rk1, int f, int dg, int lane, int w_lo, int h_lo,
-                                             int h_hi, int r_begin, int n_iters, int H, int W, int D) {
+__device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0, float rank_eps,
+                                             int f, int dg, int lane, int w_lo, int h_lo, int h_hi, int r_begin,
+                                             int n_iters, int H, int W, int D) {
   constexpr int BS = 9, TAIL = 4, STEP = lcm_ce(6, kTRows);
   constexpr bool RANK = (MODE & kRank) != 0, STORE = (MODE & kNoStore) == 0;
-  static_assert((STEP / kTRows) % 2 == 0, "chunk parity must be a compile-time function of the unrolled row");
   const long HW = (long)H * W;
   const int d_base = dg * kTDG + WAVE * kTND;
   // per-lane column arithmetic is kept to ONE register, 4 * lane: everything else about the column tile (w_lo) goes
@@ -1072,30 +1079,34 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       for (int k = 0; k < kTRankFloats / 256; ++k) *(f32x4*)(rank_lds + 256 * k + 4 * lane) = ninf;
     }
   }
-  // rows of chunk `ch` (slot parity `par`) whose read-out falls to this wavefront: slots -> partial planes, reset
-  auto rank_readout = [&](int ch, int par) {
+  // rows of chunk `ch` whose read-out falls to this wavefront: slots -> partial plane, reset
+  auto rank_readout = [&](int ch) {
+    float* sb = rank_lds + (ch % kTRankBufs) * (kTRows * 2 * 256) + lane;
 #pragma unroll
     for (int s = 0; s < kTRows; ++s) {
       const int hh = r_begin + ch * kTRows + s - TAIL;
       if (hh >= h_lo && hh < h_hi && (s + ch) % n_active == WAVE) {      // wave-uniform
-        float* sl = rank_lds + ((par * kTRows + s) * 2) * 256 + lane;
+        float* sl = sb + s * 2 * 256;
         f32x4 t, q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { t[i] = sl[64 * i]; q[i] = sl[256 + 64 * i]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sl[64 * i] = -INFINITY; sl[256 + 64 * i] = -INFINITY; }
-        if (lane_out) {
-          // uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane 64-bit pointers to keep
-          __builtin_nontemporal_store(t, (f32x4*)(rk0 + ((long)hh * W + w_lo) + l4));
-          __builtin_nontemporal_store(q, (f32x4*)(rk1 + ((long)hh * W + w_lo) + l4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // (a group the run mask emptied keeps top = -inf: no flag, or the word would turn into a NaN)
+          const int close = (rank_eps >= 0.f && t[i] > -INFINITY && q[i] >= t[i] - rank_margin(rank_eps, t[i])) ? 16 : 0;
+          t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
         }
+        // uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane 64-bit pointers to keep
+        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + ((long)hh * W + w_lo) + l4));
       }
     }
   };
-  // The runner-up update needs the value the first atomic returns: it is issued at the start of the next row (or at
-  // the chunk barrier), behind that row's operand reads -- LDS answers in order, so the returns are there by the time
-  // the operands are -- instead of being waited for on its own.  Unconditional (a row without outputs leaves -inf
-  // here, a no-op for the maximum): a flag would keep these twelve registers alive across the whole loop.
+  // The runner-up update needs the value the first atomic returns: it is issued at the start of the next row, behind
+  // that row's operand reads -- LDS answers in order, so the returns are there by the time the operands are --
+  // instead of being waited for on its own.  Unconditional (a row without outputs leaves -inf here, a no-op for the
+  // maximum): a flag would keep these twelve registers alive across the whole loop.
   float rk_hi[4], rk_lo[4], rk_old[4];
   float* rk_sl = rank_lds + lane;
 #pragma unroll
@@ -1119,9 +1130,8 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
     for (int u = 0; u < STEP; ++u) {
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
-      const int par = (u / kTRows) & 1;                            // parity of `chunk` (two chunks per iteration)
       if constexpr (RANK) {
-        if ((u % kTRows) == 0 && chunk > 0) rank_readout(chunk - 1, par ^ 1);
+        if ((u % kTRows) == 0 && chunk > 1) rank_readout(chunk - 2);
       }
       // Phase A, every row: products and the vertical 3+3+3 rings of both disparities (needs only the two value
       // quads).  Phase B, output rows only (wave-uniform branch; the (bs-1) warm-up rows of a band skip it):
@@ -1138,9 +1148,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       const float* hqp = lds + hq_o;                               // halo sums of (wave 0, j 0) on this lane's side
       f32x4 qa = quad(own);
       f32x4 qb0 = quad(own + kTOffB + 4 * kQ), qb1 = quad(own + kTOffB + 4 * (kQ + 1));
-      if constexpr (RANK) {
-        if ((u % kTRows) != 0) rank_second();                      // previous row of this chunk (flushed at the barrier otherwise)
-      }
+      if constexpr (RANK) rank_second();                           // previous row (possibly of the previous chunk)
       asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
       const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
       const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
@@ -1158,13 +1166,6 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           T[j][i][u % 6] = t3;
         }
       if (row_out) {
-        // is this row's fully clamped run window listed for the fix-up pass (NaN deviation)?  It sits in the staged
-        // pattern-side array at column x = -TAIL, slot dg * kTDG + kTDG - 1 of the first column tile (wave-uniform)
-        int run_listed = 0;
-        if (RANK && run_masks && dg * kTDG + kTDG - 1 < kTSpanPad)
-          run_listed = (__builtin_amdgcn_readfirstlane(__float_as_int(
-                            lds[((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + kTOffB + 2 * kTSpanPad + dg * kTDG + kTDG - 1])) &
-                        0x7fffffff) > 0x7f800000;                  // uniform address: no per-lane register to keep
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
         f32x4 qm0 = quad(own + kTOffB + kTSpanPad + 4 * kQ), qm1 = quad(own + kTOffB + kTSpanPad + 4 * (kQ + 1));
         f32x4 qs0 = quad(own + kTOffB + 2 * kTSpanPad + 4 * kQ), qs1 = quad(own + kTOffB + 2 * kTSpanPad + 4 * (kQ + 1));
@@ -1216,15 +1217,15 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             for (int i = 0; i < 4; ++i) {
               float k = rank_key(val[i], 15 - (WAVE * kTND + j));
               if (d >= D) k = -INFINITY;                           // wave-uniform
-              // d > w + TAIL: copy of the run's first element; d == w + TAIL with a listed run window: left to the
-              // merge.  (scalar left-hand side: no per-lane column arithmetic)
-              if (run_masks && d - TAIL - i + run_listed - w_lo > (int)l4) k = -INFINITY;
+              // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
+              // the run's window is listed).  Loop-invariant compare with a scalar left-hand side.
+              if (run_masks && d - TAIL - i - w_lo > (int)l4) k = -INFINITY;
               key[j][i] = k;
             }
           }
         }
         if constexpr (RANK) {
-          rk_sl = rank_lds + ((par * kTRows + (u % kTRows)) * 2) * 256 + lane;
+          rk_sl = rank_lds + (((chunk % kTRankBufs) * kTRows + (u % kTRows)) * 2) * 256 + lane;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // NaN keys (scores of listed windows) drop out: v_max returns the other operand, med3 with a NaN its min3
@@ -1238,21 +1239,31 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
       }
       if (last_of_chunk) {
-        if constexpr (RANK) rank_second();                         // the slots must be complete at the barrier
+        if constexpr (RANK) {
+          // the band's last chunk has no next row to ride on: complete its slots before its barrier (wave-uniform)
+          if (it == n_iters - 1 && u == STEP - 1) {
+            rank_second();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
+          }
+        }
         wait_lgkmcnt0();
         wg_barrier();
         ++chunk;
       }
     }
   }
-  if constexpr (RANK) rank_readout(chunk - 1, (chunk - 1) & 1);
+  if constexpr (RANK) {
+    rank_readout(chunk - 2);                                       // n_chunks is even and >= 2
+    rank_readout(chunk - 1);
+  }
 }
 
 template <bool ACCUM, int MODE>
 __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
-    float* __restrict__ out, float* __restrict__ rank0, float* __restrict__ rank1, int C, int c, int H, int W, int D,
+    float* __restrict__ out, float* __restrict__ rank0, float rank_eps, int C, int c, int H, int W, int D,
     int band_rows, int n_dgroups, int Wp, int W1, int xoff) {
   constexpr int HALF = 4, TAIL = 4, STEP = lcm_ce(6, kTRows), CPI = STEP / kTRows;   // chunks per outer iteration
   // ranking: [kTRankFloats] rank slots first (their addresses then fit the 16-bit DS offset), then the staging ring
@@ -1387,11 +1398,10 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     return;
   }
 
-  // partial planes of this (frame, disparity group)
+  // partial plane of this (frame, disparity group)
   float* rk0 = (MODE & kRank) ? rank0 + (long)blockIdx.z * H * W : nullptr;
-  float* rk1 = (MODE & kRank) ? rank1 + (long)blockIdx.z * H * W : nullptr;
 #define CTD_TCASE(WV) \
-  case WV: t256_consume<ACCUM, MODE, WV>(lds, out, rk0, rk1, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
+  case WV: t256_consume<ACCUM, MODE, WV>(lds, out, rk0, rank_eps, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
   switch (wave) {
     CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5) CTD_TCASE(6)
     default: break;
@@ -1462,24 +1472,24 @@ static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, i
   const size_t nlist = align_up((size_t)frames * H * W * sizeof(int64_t), 256);
   char* p = (char*)base + offset;
   rp.k0 = (float*)p;
-  rp.k1 = (float*)(p + npart);
-  rp.dirty = (unsigned char*)(p + 2 * npart);
-  rp.n_hard = (unsigned*)(p + 2 * npart + ndirty);
-  rp.hard_list = (int64_t*)(p + 2 * npart + ndirty + 256);
-  rp.patches = (const unsigned long long*)(p + 2 * npart + ndirty + 256 + nlist);
+  rp.dirty = (unsigned char*)(p + npart);
+  rp.n_hard = (unsigned*)(p + npart + ndirty);
+  rp.hard_list = (int64_t*)(p + npart + ndirty + 256);
+  rp.patches = (const unsigned long long*)(p + npart + ndirty + 256 + nlist);
   rp.patch_capacity = (unsigned)((size_t)frames * H * W);
   rp.n_patches = nullptr;
-  rp.best_scratch = (float*)(p + 2 * npart + ndirty + 256 + 2 * nlist);
-  rp.bytes = offset + 2 * npart + ndirty + 256 + 2 * nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
+  rp.best_scratch = (float*)(p + npart + ndirty + 256 + 2 * nlist);
+  rp.bytes = offset + npart + ndirty + 256 + 2 * nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
   rp.run_flag = nullptr; rp.run_flag_frame_stride = 0; rp.run_flag_row_stride = 0; rp.run_vals = nullptr;
+  rp.eps = 0.f;
   return rp;
 }
 
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off) {
   const size_t base = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern).bytes;
   const RankPlan rp = rank_plan(nullptr, base, frames, H, W, D);
-  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.k1; off[2] = (size_t)rp.dirty; off[3] = (size_t)rp.n_hard;
-  off[4] = (size_t)rp.hard_list; off[5] = (size_t)rp.n_dg;
+  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.dirty; off[2] = (size_t)rp.n_hard; off[3] = (size_t)rp.hard_list;
+  off[4] = (size_t)rp.n_dg;
 }
 
 size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern) {
@@ -1530,7 +1540,7 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
         CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       timing_begin(stream);
       hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
-                         rank ? rank->k0 : nullptr, rank ? rank->k1 : nullptr, C, c, H, W, D, band_rows, n_dg, ws.Wp,
+                         rank ? rank->k0 : nullptr, rank ? rank->eps : -1.f, C, c, H, W, D, band_rows, n_dg, ws.Wp,
                          ws.W1, ws.xoff);
       timing_end(stream, W);
       CTD_LAUNCH_CHECK();
@@ -1581,6 +1591,7 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
 
 // `rank` non-null: also rank every pixel's scores inside the volume kernel (see t256_consume) and fill *rank with
 // the buffers rank_merge_f32 (argmax_rerank.hip) needs; `out` may then be null (no volume is materialised).
+// rank->eps is an input: the re-ranking margin the partials are flagged against.
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
@@ -1591,7 +1602,9 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   size_t need = ws.bytes;
   if (rank) {
+    const float eps = rank->eps;
     *rank = rank_plan(workspace, ws.bytes, frames, H, W, D);
+    rank->eps = eps;
     need = rank->bytes;
     rank->run_flag = ws.v1 + (-(bs - 1 - bs / 2) + ws.xoff);     // deviation plane at the run window's column
     rank->run_flag_frame_stride = per_frame ? (long)C * H * ws.W1 : 0;

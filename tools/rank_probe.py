@@ -19,12 +19,12 @@ st = L.ctd_xcorrvol_argmax_f32(x.data_ptr(), p.data_ptr(), 0, vol.data_ptr(), id
                                1e-5, ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream().cuda_stream)
 assert st == 0, st
 torch.cuda.synchronize()
-off = (ctypes.c_size_t * 6)()
+off = (ctypes.c_size_t * 5)()
 L.ctd_xcorrvol_rank_layout(N, H, W, D, 0, off)
-n_hard = int(ws[off[3]:off[3] + 4].view(torch.int32).item())
-dirty = ws[off[2]:off[2] + N * H * W].view(N, H, W)
+n_hard = int(ws[off[2]:off[2] + 4].view(torch.int32).item())
+dirty = ws[off[1]:off[1] + N * H * W].view(N, H, W)
 print("pixels", N * H * W, "listed for re-scoring", n_hard, "dirty", int(dirty.sum()))
-hl = ws[off[4]:off[4] + 8 * n_hard].view(torch.int64)
+hl = ws[off[3]:off[3] + 8 * n_hard].view(torch.int64)
 w = (hl % W).cpu().numpy(); h = ((hl // W) % H).cpu().numpy()
 print("listed by column: w<124:", int((w < 124).sum()), " w>=124:", int((w >= 124).sum()))
 # true top-2 gap statistics from the volume (run masked)
@@ -33,6 +33,5 @@ v = vol.masked_fill(dd > ww + 4, float("-inf"))
 t2 = v.topk(2, dim=1).values
 gap = (t2[:, 0] - t2[:, 1])
 print("pixels with fast gap < 1e-5:", int((gap < 1e-5).sum()), " < 1.4e-5:", int((gap < 1.4e-5).sum()))
-k0 = ws[off[0]:off[0] + 4 * N * off[5] * H * W].view(torch.float32).view(N, off[5], H, W)
-k1 = ws[off[1]:off[1] + 4 * N * off[5] * H * W].view(torch.float32).view(N, off[5], H, W)
-print("NaN keys:", int(torch.isnan(k0).sum()), int(torch.isnan(k1).sum()), " k1>k0:", int((k1 > k0).sum()), "k1==k0", int((k1 == k0).sum()))
+k0 = ws[off[0]:off[0] + 4 * N * off[4] * H * W].view(torch.float32).view(N, off[4], H, W)
+print("NaN keys:", int(torch.isnan(k0).sum()), " close flags:", int(((k0.view(torch.int32) & 16) != 0).sum()))

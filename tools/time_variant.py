@@ -1,0 +1,36 @@
+"""Times the ranked volume kernel of an experimental build of the library (tools/variants/*.so, never shipped):
+    python tools/time_variant.py [path/to/lib.so ...]"""
+import ctypes, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import workloads
+
+def run(path):
+    from connecting_the_dots_amd import _lib
+    _lib._lib = None
+    if path:
+        _lib.LIB_PATH = path
+    from connecting_the_dots_amd import torchext as te
+    L = _lib.lib()
+    H, W, D, N = 432, 512, 128, 16
+    fr = torch.from_numpy(np.stack([workloads.uniform_frame(1234 + i, H, W) for i in range(N)])).cuda()
+    pat = torch.from_numpy(workloads.syn_dot_pattern(H, W, seed=42)[None, None]).cuda()
+    x, _ = te.lcn(fr, 5, 0.05)
+    p, _ = te.lcn(pat, 5, 0.05)
+    p = p[0].contiguous()
+    for _ in range(5):
+        te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    L.ctd_kernel_timing_enable(0)
+    ms, cols = ctypes.c_double(0), ctypes.c_int(0)
+    n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
+    print("%-40s volume kernel %.4f ms (%d launches)   argmax call %.4f ms" % (os.path.basename(path or "in-tree"), ms.value, n, dt * 1e3), flush=True)
+
+for p in (sys.argv[1:] or [""]):
+    run(p)
