@@ -1032,6 +1032,14 @@ __device__ inline float vmaxf_raw(float a, float b) {         // v_max_f32 witho
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// min(a, b) that is -inf when either is NaN: v_med3_f32 returns min3 of its operands when one of them is a NaN.
+// (__builtin_amdgcn_fmed3f with a constant -inf is folded by clang into canonicalise + v_min: 3 instructions, and the
+// wrong NaN rule.)
+__device__ inline float vmin_nan_low(float a, float b) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(-INFINITY));
+  return r;
+}
 
 template <bool ACCUM, int MODE, int WAVE>
 __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0, float rank_eps,
@@ -1125,6 +1133,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
     return;
   }
   int chunk = 0;
+  f32x4 qa, qb0, qb1;                                              // value quads of the row (frame, pattern x 2)
   for (int it = 0; it < n_iters; ++it) {
 #pragma unroll
     for (int u = 0; u < STEP; ++u) {
@@ -1146,9 +1155,14 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       int hq_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + kTOffH + halo_side * 4;
       asm("" : "+v"(hq_o));
       const float* hqp = lds + hq_o;                               // halo sums of (wave 0, j 0) on this lane's side
-      f32x4 qa = quad(own);
-      f32x4 qb0 = quad(own + kTOffB + 4 * kQ), qb1 = quad(own + kTOffB + 4 * (kQ + 1));
-      if constexpr (RANK) rank_second();                           // previous row (possibly of the previous chunk)
+      // The value quads of a chunk's first row are read here; those of its other rows were requested at the end of
+      // the previous row, AHEAD of that row's returning atomics: LDS answers in order, and a read queued behind the
+      // atomics would make phase A wait for their round trip.
+      if ((u % kTRows) == 0) {
+        qa = quad(own);
+        qb0 = quad(own + kTOffB + 4 * kQ);
+        qb1 = quad(own + kTOffB + 4 * (kQ + 1));
+      }
       asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
       const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
       const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
@@ -1165,6 +1179,15 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           x[j][i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
           T[j][i][u % 6] = t3;
         }
+      // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
+      if constexpr (RANK) rank_second();
+      auto prefetch_next = [&]() {                                 // next row of the same chunk: one ring row further
+        if (!last_of_chunk) {
+          qa = quad(own + kTPack);
+          qb0 = quad(own + kTPack + kTOffB + 4 * kQ);
+          qb1 = quad(own + kTPack + kTOffB + 4 * (kQ + 1));
+        }
+      };
       if (row_out) {
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
         f32x4 qm0 = quad(own + kTOffB + kTSpanPad + 4 * kQ), qm1 = quad(own + kTOffB + kTSpanPad + 4 * (kQ + 1));
@@ -1213,30 +1236,38 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, (f32x4*)o);
           }
           if constexpr (RANK) {
+            if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float k = rank_key(val[i], 15 - (WAVE * kTND + j));
-              if (d >= D) k = -INFINITY;                           // wave-uniform
-              // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
-              // the run's window is listed).  Loop-invariant compare with a scalar left-hand side.
-              if (run_masks && d - TAIL - i - w_lo > (int)l4) k = -INFINITY;
-              key[j][i] = k;
+              for (int i = 0; i < 4; ++i) {
+                float k = rank_key(val[i], 15 - (WAVE * kTND + j));
+                // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
+                // the run's window is listed).  Loop-invariant compare: hoisted into a lane mask.
+                if (run_masks && d - TAIL - i - w_lo > (int)l4) k = -INFINITY;
+                key[j][i] = k;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) key[j][i] = -INFINITY;
             }
           }
         }
+        prefetch_next();
         if constexpr (RANK) {
           rk_sl = rank_lds + (((chunk % kTRankBufs) * kTRows + (u % kTRows)) * 2) * 256 + lane;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // NaN keys (scores of listed windows) drop out: v_max returns the other operand, med3 with a NaN its min3
             rk_hi[i] = vmaxf_raw(key[0][i], key[1][i]);
-            rk_lo[i] = __builtin_amdgcn_fmed3f(key[0][i], key[1][i], -INFINITY);
+            rk_lo[i] = vmin_nan_low(key[0][i], key[1][i]);
             rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
-      } else if constexpr (RANK) {
+      } else {
+        prefetch_next();
+        if constexpr (RANK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
+          for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
+        }
       }
       if (last_of_chunk) {
         if constexpr (RANK) {

@@ -30,7 +30,16 @@ def run(path):
     L.ctd_kernel_timing_enable(0)
     ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
-    print("%-40s volume kernel %.4f ms (%d launches)   argmax call %.4f ms" % (os.path.basename(path or "in-tree"), ms.value, n, dt * 1e3), flush=True)
+    L.ctd_kernel_timing_enable(1)
+    for _ in range(10):
+        te.xcorrvol_batch(x, p, D, 9, algo="fast")
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_enable(0)
+    ms2 = ctypes.c_double(0)
+    L.ctd_kernel_timing_collect(ctypes.byref(ms2), ctypes.byref(cols))
+    print("%-28s ranked volume kernel %.4f ms (%d launches)  argmax call %.4f ms   plain volume kernel %.4f ms" % (
+        os.path.basename(path or "in-tree"), ms.value, n, dt * 1e3, ms2.value), flush=True)
 
-for p in (sys.argv[1:] or [""]):
-    run(p)
+for _ in range(3):                      # interleaved repetitions: box-to-box and run-to-run spread shows up
+    for p in (sys.argv[1:] or [""]):
+        run(p)
