@@ -1041,10 +1041,15 @@ __device__ inline float vmin_nan_low(float a, float b) {
   return r;
 }
 
-template <bool ACCUM, int MODE, int WAVE>
+// KS = sub-quad shift of the wavefront's pattern-side operands, (12 - 2 * wave) % 4: 0 for even consumer wavefronts, 2
+// for odd ones.  Everything else that depends on the wavefront index (quad offset, halo slot, key tags, read-out
+// duty) is a run-time scalar, so the kernel carries TWO copies of the consumer loop, not seven: with one copy per
+// wavefront the seven hot loops of a workgroup (plus the loader's) are a 77 KB instruction working set (166 KB with
+// ranking) against a 64 KB instruction cache shared by two CUs.
+template <bool ACCUM, int MODE, int KS>
 __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0, float rank_eps,
-                                             int f, int dg, int lane, int w_lo, int h_lo, int h_hi, int r_begin,
-                                             int n_iters, int H, int W, int D) {
+                                             int WAVE, int f, int dg, int lane, int w_lo, int h_lo, int h_hi,
+                                             int r_begin, int n_iters, int H, int W, int D) {
   constexpr int BS = 9, TAIL = 4, STEP = lcm_ce(6, kTRows);
   constexpr bool RANK = (MODE & kRank) != 0, STORE = (MODE & kNoStore) == 0;
   const long HW = (long)H * W;
@@ -1064,12 +1069,13 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
 #pragma unroll
       for (int k = 0; k < 6; ++k) T[j][i][k] = 0.f;
     }
-  constexpr int kOff0 = (kTDG - 1) - WAVE * kTND;                  // span slot offset of disparity j = 0
-  constexpr int kQ = (kOff0 - 1) / 4, kS = (kOff0 - 1) % 4;       // disparity j = 1 sits one span slot below j = 0:
-                                                                   // both come out of the same two aligned quads
-  static_assert(kTND == 2, "two disparities per lane");
+  const int kOff0 = (kTDG - 1) - WAVE * kTND;                      // span slot offset of disparity j = 0
+  const int kQ = (kOff0 - 1) / 4;                                  // disparity j = 1 sits one span slot below j = 0:
+  constexpr int kS = KS;                                           // both come out of the same two aligned quads
+  static_assert(kTND == 2 && (kTDG - 2) % 4 == 0, "two disparities per lane; (kOff0 - 1) % 4 alternates 0, 2");
+  const int tag0 = 15 - WAVE * kTND;                               // key tag of disparity j = 0 (j = 1: one less)
   // halo sums: lane 0 takes the left quad's suffix sums, lane 63 the right quad's prefix sums, others zero
-  const int halo_side = lane == 63 ? 1 : 0;
+  const int halo4 = lane == 63 ? 4 : 0;
   // applied as a multiplicative mask: hipcc 7.2 miscompiles the select form `halo_lane ? hq[i] : 0.f` here
   // (it zeroes the value for every lane < 63, lane 0 included)
   const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;
@@ -1106,8 +1112,10 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           const int close = (rank_eps >= 0.f && t[i] > -INFINITY && q[i] >= t[i] - rank_margin(rank_eps, t[i])) ? 16 : 0;
           t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
         }
-        // uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane 64-bit pointers to keep
-        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + ((long)hh * W + w_lo) + l4));
+        // opaque uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane pointer to keep
+        float* rbase = rk0 + ((long)hh * W + w_lo);
+        asm("" : "+s"(rbase));
+        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rbase + l4));
       }
     }
   };
@@ -1149,19 +1157,31 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       // One per-lane base per row, made opaque: every LDS operand of the row is then base + 16-bit immediate.  (Left
       // alone the compiler hoists one base VGPR per ring row whose offset does not fit the immediate -- with the
       // rank slots in front of the ring that is 3 spilled registers, reloaded behind a vmcnt(0) wait every row.)
-      int own_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + 4 * (lane + 1);
+      // (Likewise every address below is an opaque per-row SCALAR plus one of two loop-invariant lane registers, l4 or
+      // halo4: anything the compiler can prove loop-invariant it hoists into a register of its own, and there are none
+      // to spare.)
+      int row_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + 4;
+      asm("" : "+s"(row_o));
+      int own_o = row_o + (int)l4;
       asm("" : "+v"(own_o));
       const float* own = lds + own_o;                              // own quad after the left halo
-      int hq_o = ((chunk % kTBufs) * kTRows + (u % kTRows)) * kTPack + kTOffH + halo_side * 4;
+      int pat_s = row_o + kTOffB + 4 * kQ;
+      asm("" : "+s"(pat_s));
+      int pat_o = pat_s + (int)l4;
+      asm("" : "+v"(pat_o));
+      const float* pat = lds + pat_o;                              // first of the lane's two pattern-side quads
+      int hq_s = row_o - 4 + kTOffH + WAVE * (kTND * 2 * 4);
+      asm("" : "+s"(hq_s));
+      int hq_o = hq_s + halo4;
       asm("" : "+v"(hq_o));
-      const float* hqp = lds + hq_o;                               // halo sums of (wave 0, j 0) on this lane's side
+      const float* hqp = lds + hq_o;                               // halo sums of (this wave, j 0) on this lane's side
       // The value quads of a chunk's first row are read here; those of its other rows were requested at the end of
       // the previous row, AHEAD of that row's returning atomics: LDS answers in order, and a read queued behind the
       // atomics would make phase A wait for their round trip.
       if ((u % kTRows) == 0) {
         qa = quad(own);
-        qb0 = quad(own + kTOffB + 4 * kQ);
-        qb1 = quad(own + kTOffB + 4 * (kQ + 1));
+        qb0 = quad(pat);
+        qb1 = quad(pat + 4);
       }
       asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
       const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
@@ -1184,14 +1204,14 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       auto prefetch_next = [&]() {                                 // next row of the same chunk: one ring row further
         if (!last_of_chunk) {
           qa = quad(own + kTPack);
-          qb0 = quad(own + kTPack + kTOffB + 4 * kQ);
-          qb1 = quad(own + kTPack + kTOffB + 4 * (kQ + 1));
+          qb0 = quad(pat + kTPack);
+          qb1 = quad(pat + kTPack + 4);
         }
       };
       if (row_out) {
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
-        f32x4 qm0 = quad(own + kTOffB + kTSpanPad + 4 * kQ), qm1 = quad(own + kTOffB + kTSpanPad + 4 * (kQ + 1));
-        f32x4 qs0 = quad(own + kTOffB + 2 * kTSpanPad + 4 * kQ), qs1 = quad(own + kTOffB + 2 * kTSpanPad + 4 * (kQ + 1));
+        f32x4 qm0 = quad(pat + kTSpanPad), qm1 = quad(pat + kTSpanPad + 4);
+        f32x4 qs0 = quad(pat + 2 * kTSpanPad), qs1 = quad(pat + 2 * kTSpanPad + 4);
         float me[8], se[8];
         float key[kTND][4];
 #pragma unroll
@@ -1214,7 +1234,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
 #pragma unroll
             for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
           }
-          f32x4 hq = quad(hqp + (WAVE * kTND + j) * 2 * 4);
+          f32x4 hq = quad(hqp + j * 2 * 4);
           asm("" : "+v"(hq));
           float val[4];
 #pragma unroll
@@ -1226,7 +1246,9 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           }
           const int d = d_base + j;
           if (STORE && lane_out && d < D) {
-            float4* o = (float4*)(vol + ((long)d * HW + (long)h * W) + l4);
+            float* obase = vol + ((long)d * HW + (long)h * W);
+            asm("" : "+s"(obase));
+            float4* o = (float4*)(obase + l4);
             float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
             if (ACCUM) {
               const float4 old = *o;
@@ -1239,7 +1261,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                float k = rank_key(val[i], 15 - (WAVE * kTND + j));
+                float k = rank_key(val[i], tag0 - j);
                 // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
                 // the run's window is listed).  Loop-invariant compare: hoisted into a lane mask.
                 if (run_masks && d - TAIL - i - w_lo > (int)l4) k = -INFINITY;
@@ -1300,7 +1322,8 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
   // ranking: [kTRankFloats] rank slots first (their addresses then fit the 16-bit DS offset), then the staging ring
   extern __shared__ float lds_all[];
   float* lds = lds_all + ((MODE & kRank) ? kTRankFloats : 0);   // [kTBufs][kTRows][kTPack]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index feeds scalar arithmetic (disparity base, LDS offsets, key tags): make it a scalar for the compiler
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
   const int w_lo = blockIdx.x * kTTile;
   const int h_lo = blockIdx.y * band_rows;
@@ -1431,13 +1454,11 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
 
   // partial plane of this (frame, disparity group)
   float* rk0 = (MODE & kRank) ? rank0 + (long)blockIdx.z * H * W : nullptr;
-#define CTD_TCASE(WV) \
-  case WV: t256_consume<ACCUM, MODE, WV>(lds, out, rk0, rank_eps, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D); break;
-  switch (wave) {
-    CTD_TCASE(0) CTD_TCASE(1) CTD_TCASE(2) CTD_TCASE(3) CTD_TCASE(4) CTD_TCASE(5) CTD_TCASE(6)
-    default: break;
-  }
-#undef CTD_TCASE
+  // two copies of the consumer loop: the sub-quad shift of the pattern-side operands alternates with the wave index
+  if (wave & 1)
+    t256_consume<ACCUM, MODE, (kTDG - 2 - kTND) % 4>(lds, out, rk0, rank_eps, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
+  else
+    t256_consume<ACCUM, MODE, (kTDG - 2) % 4>(lds, out, rk0, rank_eps, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
 }
 
 struct FastWorkspace {
