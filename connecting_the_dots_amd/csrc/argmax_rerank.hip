@@ -105,6 +105,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // rewritten as "is on the work list" flags for rank_patch_check_kernel.
 __device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }   // as in ncc_fast.hip
 
+// Appends `item` to a work list for the lanes with `take` set: one atomic per wavefront (thousands of lanes bumping
+// one counter one by one cost the merge kernel as much as its memory traffic).
+__device__ inline void worklist_push(bool take, int64_t item, unsigned* __restrict__ counter, int64_t* __restrict__ list) {
+  const unsigned long long m = __ballot(take);
+  if (m == 0) return;                                          // wave-uniform
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  unsigned base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+  base = __shfl(base, leader);
+  if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = item;
+}
+
 __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, int n_dg, int dg_size,
                                                          const float* __restrict__ run_flag,
                                                          long run_flag_frame_stride, long run_flag_row_stride,
@@ -166,10 +178,8 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
                                      !(m > -INFINITY));
     idx[p0 + k] = d;
     bq[k] = b;
-    if (hard) {
-      hard_list[atomicAdd(n_hard, 1u)] = p0 + k;
-      listed4 |= 1u << (8 * k);
-    }
+    worklist_push(hard, p0 + k, n_hard, hard_list);
+    if (hard) listed4 |= 1u << (8 * k);
   }
   *(unsigned*)(dirty + p0) = listed4;
   *(f4*)(best + p0) = bq;
@@ -184,14 +194,21 @@ __global__ __launch_bounds__(256) void rank_patch_check_kernel(const unsigned* _
                                                                unsigned* __restrict__ n_hard,
                                                                int64_t* __restrict__ hard_list) {
   const unsigned n = min(*n_patches, capacity);
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const unsigned long long e = patches[i];
-    const unsigned pix = (unsigned)(e >> 32);
-    const float val = __int_as_float((int)(unsigned)e), m = best[pix];
-    if (!(val < m - rank_margin(eps, m))) {                   // also NaN
-      const unsigned bit = 1u << (8 * (pix & 3));
-      if ((atomicOr(flags + (pix >> 2), bit) & bit) == 0) hard_list[atomicAdd(n_hard, 1u)] = pix;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {      // whole wavefronts stay in the loop
+    const unsigned i = i0 + threadIdx.x;
+    bool take = false;
+    unsigned pix = 0;
+    if (i < n) {
+      const unsigned long long e = patches[i];
+      pix = (unsigned)(e >> 32);
+      const float val = __int_as_float((int)(unsigned)e), m = best[pix];
+      if (!(val < m - rank_margin(eps, m))) {                 // also NaN
+        const unsigned bit = 1u << (8 * (pix & 3));
+        take = (atomicOr(flags + (pix >> 2), bit) & bit) == 0;
+      }
     }
+    worklist_push(take, pix, n_hard, hard_list);
   }
 }
 

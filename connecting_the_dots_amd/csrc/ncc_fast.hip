@@ -52,9 +52,10 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
 constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
+constexpr double kDevFloor = 6e-3;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 3e-4 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
-// out_mean = window mean - cval, out_dev = sqrt(sum of squared deviations), out_img = img - cval
+// out_mean = window mean - cval, out_dev = 1 / sqrt(sum of squared deviations) (NaN: listed window), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
 // cval = f64 window mean at the image centre, recomputed identically by every workgroup.
 // One launch serves the frames (job a) and the pattern (job b): blockIdx.z < a.nimg -> image blockIdx.z of job a,
@@ -171,17 +172,18 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     // (see there), which recomputes EVERY output they take part in:
     //  * deviation small against the offset from the centring constant: cov = S_ab - n*ma*mb cancels in f32;
     //  * (nearly) flat window, deviation below 2e-4 of its mean: the reference's own value is then decided by
-    //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it.
+    //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it; or deviation
+    //    below kDevFloor, where the 1e-8 of the reference's denominator stops being a small correction.
     // A listed window's deviation is stored as NaN: the fast kernels then produce NaN for exactly the outputs the
     // fix-up pass overwrites, and a NaN score never enters the in-kernel ranking (t256_consume).
     const double mc = mean - (double)cval;
-    const bool flat = 4e-8 * n * mean * mean > var;
+    const bool flat = 4e-8 * n * mean * mean > var || var < kDevFloor * kDevFloor;
     const bool listed = flat || n * mc * mc > kFlagRatio * var;
-    const float dev = (float)sqrt(var > 0 ? var : 0.0);
+    const float rdev = (float)(1.0 / sqrt(var > 0 ? var : 1.0));  // reciprocal deviation (see ncc_inv_norm)
     const long o = ((long)img_idx * H + h) * W_out + xi;
     const int col = xi + x_start;
     out_mean[o] = (float)mc;
-    out_dev[o] = listed ? __int_as_float(0x7fc00000) : dev;
+    out_dev[o] = listed ? __int_as_float(0x7fc00000) : rdev;
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     if (dirty && col >= 0 && col < W) dirty[((long)img_idx * H + h) * W + col] = 0;
     if (listed && col >= col_lo && col < col_hi) {
@@ -434,6 +436,16 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   }
 }
 
+// 1 / (sa * sb + 1e-8) from the RECIPROCAL deviations the pre-pass stores: t = ra * rb, times (1 - 1e-8 t), the
+// first two terms of 1 / (1 + 1e-8 t).  Three full-rate instructions (+ the multiply by cov) instead of an fma, a
+// quarter-rate v_rcp_f32 and a multiply: the consumer loops are VALU-bound and the reciprocal was a fifth of their
+// issue slots.  The neglected terms are (1e-8 t)^2 relative: below 1e-7 because the pre-pass lists every window whose
+// deviation is under kDevFloor (t <= 1 / kDevFloor^2), and listed windows go through the fix-up pass.
+__device__ inline float ncc_inv_norm(float ra, float rb) {
+  const float t = ra * rb;
+  return t * fmaf(t, -1e-8f, 1.f);
+}
+
 // cross-lane helpers (wave64) -----------------------------------------------------------
 __device__ inline float lane_prev1(float x) {   // result[l] = x[l-1]
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
@@ -632,8 +644,7 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
         }
         const float s = lane_window_sum<BS>(v, lane);
         const float cov = fmaf(nma, mbv[j], s);
-        const float den = fmaf(sav, sbv[j], 1e-8f);
-        float val = cov * __builtin_amdgcn_rcpf(den);
+        float val = cov * ncc_inv_norm(sav, sbv[j]);
         const int d = d_base + j;
         if (lane_out && row_out && d < D) {
           const long o = (long)d * HW + (long)h * W + w0;
@@ -846,8 +857,7 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
 #pragma unroll
         for (int i = 0; i < kWCols; ++i) {
           const float cov = fmaf(nma[i], cur.mb[j][i], s[i]);
-          const float den = fmaf(cur.sa[i], cur.sb[j][i], 1e-8f);
-          val[i] = cov * __builtin_amdgcn_rcpf(den);
+          val[i] = cov * ncc_inv_norm(cur.sa[i], cur.sb[j][i]);
         }
         const int d = d_base + j;
         if (row_out && lane_out && d < D) {
@@ -1113,9 +1123,9 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
         }
         // opaque uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane pointer to keep
-        float* rbase = rk0 + ((long)hh * W + w_lo);
-        asm("" : "+s"(rbase));
-        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rbase + l4));
+        long roff = (long)hh * W + w_lo;                            // (an opaque POINTER would turn the store into a flat one)
+        asm("" : "+s"(roff));
+        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + roff + l4));
       }
     }
   };
@@ -1212,6 +1222,9 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
         f32x4 qm0 = quad(pat + kTSpanPad), qm1 = quad(pat + kTSpanPad + 4);
         f32x4 qs0 = quad(pat + 2 * kTSpanPad), qs1 = quad(pat + 2 * kTSpanPad + 4);
+        // without ranking the next row's value quads are requested here, under the whole of phase B; with it there
+        // are no 12 registers to spare until the normalisation is done (see below)
+        if constexpr (!RANK) prefetch_next();
         float me[8], se[8];
         float key[kTND][4];
 #pragma unroll
@@ -1241,14 +1254,13 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           for (int i = 0; i < 4; ++i) {
             const float sh = fmaf(halo_mask, hq[i], sj[i]);
             const float cov = fmaf(-nf * qma[i], me[kS + (1 - j) + i], sh);
-            const float den = fmaf(qsa[i], se[kS + (1 - j) + i], 1e-8f);
-            val[i] = cov * __builtin_amdgcn_rcpf(den);
+            val[i] = cov * ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
           }
           const int d = d_base + j;
           if (STORE && lane_out && d < D) {
-            float* obase = vol + ((long)d * HW + (long)h * W);
-            asm("" : "+s"(obase));
-            float4* o = (float4*)(obase + l4);
+            long ooff = (long)d * HW + (long)h * W;
+            asm("" : "+s"(ooff));
+            float4* o = (float4*)(vol + ooff + l4);
             float4 v4 = make_float4(val[0], val[1], val[2], val[3]);
             if (ACCUM) {
               const float4 old = *o;
@@ -1260,12 +1272,13 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           if constexpr (RANK) {
             if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                float k = rank_key(val[i], tag0 - j);
+              for (int i = 0; i < 4; ++i) key[j][i] = rank_key(val[i], tag0 - j);
+              if (run_masks) {                                     // wave-uniform: first column tile only
                 // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
                 // the run's window is listed).  Loop-invariant compare: hoisted into a lane mask.
-                if (run_masks && d - TAIL - i - w_lo > (int)l4) k = -INFINITY;
-                key[j][i] = k;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (d - TAIL - i - w_lo > (int)l4) key[j][i] = -INFINITY;
               }
             } else {
 #pragma unroll
@@ -1273,7 +1286,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             }
           }
         }
-        prefetch_next();
+        if constexpr (RANK) prefetch_next();
         if constexpr (RANK) {
           rk_sl = rank_lds + (((chunk % kTRankBufs) * kTRows + (u % kTRows)) * 2) * 256 + lane;
 #pragma unroll
