@@ -5,22 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = BASELINE config 2 on every rank: 16 synthetic 512x432 frames resident in HBM ->
-LCN (r=5, eps=0.05) -> zero-mean NCC block-matching volume against the LCN'd pattern over 128
-disparities (materialised, [16,128,432,512] f32) -> argmax over disparity with reference
-(bit-exact) indices.  Frames shard across ranks with no data-path collective (weak scaling);
-the only communication is the barrier / max-reduction of the timing itself.
+N = 1 (default), one step = BASELINE config 2: 16 synthetic 512x432 frames resident in HBM -> LCN (r=5, eps=0.05)
+-> zero-mean NCC block-matching volume against the LCN'd pattern over 128 disparities (materialised,
+[16,128,432,512] f32) -> argmax over disparity with reference (bit-exact) indices.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+N > 1, one step per rank = BASELINE config 3: the same 16 frames per GPU (weak scaling, 128 frames on 8 GPUs) plus
+disparity -> depth and the two-view geometric loss on consecutive frame pairs, and the path's one exchange: an
+all-gather of the per-rank loss scalar (RCCL over xGMI).  Frames shard across ranks with no other collective.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one child process per GPU; the parent never
+touches a GPU and relays rank 0's line).  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,26 +30,107 @@ H, W, D, BS = 432, 512, 128, 9
 LCN_RADIUS, LCN_EPS = 5, 0.05
 BYTES_PER_PIXDISP = 4.0 + 8.0 / D          # 4*D*H*W volume write + both inputs read once
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+FOCAL, BASELINE_M = 567.6, 0.075           # camera of the reference's data (create_syn_data.py:228-230)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step (BASELINE config 2 / 3: 16)")
+    ap.add_argument("--algo", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--workload", default=None, choices=["config2", "config3"],
+                    help="default: config2 at one GPU, config3 (adds the geometric loss and its all-gather) at more")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-probe", action="store_true",
+                    help="skip the untimed 1-frame parity probe (the profiling scripts do: its launches would be averaged "
+                         "into the per-kernel statistics)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks (fresh interpreters; this parent has not touched a GPU), relay
+    rank 0's output, exit with the worst return code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def make_inputs(frames, rank, device):
     """Synthetic data of BASELINE.md section 3: RandomState(1234 + global frame index) uniform [0,1) frames,
     the reference's seeded synthetic dot pattern (data/commons.py:8-11) as the pattern."""
+    import numpy as np
+    import torch
     from tests import workloads
     a = np.stack([workloads.uniform_frame(1234 + rank * frames + i, H, W) for i in range(frames)])
     pat = workloads.syn_dot_pattern(H, W, seed=42)[None, None]
     return torch.from_numpy(a).to(device), torch.from_numpy(pat).to(device)
 
 
-def cpu_baseline(pattern_lcn_cpu, frame_lcn_cpu):
-    """The reference CPU path on a bounded sample: one frame of the same workload through the reference's own
-    xcorrvol_cpu (oracle/_ref, built from /root/reference by oracle/build_ref.py), else the C port."""
+def make_poses(frames, rank, device):
+    """small seeded rigid motions per frame"""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(777 + rank)
+    Rs, ts = [], []
+    for _ in range(frames):
+        ax = rs.randn(3) * 0.01
+        th = np.linalg.norm(ax)
+        k = ax / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        Rs.append(np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx)
+        ts.append(rs.randn(3) * 0.02)
+    return (torch.from_numpy(np.stack(Rs).astype(np.float32)).to(device),
+            torch.from_numpy(np.stack(ts).astype(np.float32)).to(device))
+
+
+def _ref_xcorrvol_worker(job):
+    """one frame through the reference's own xcorrvol_cpu (child process of the all-cores leg)"""
+    import torch
+    from oracle import build_ref
+    ref = build_ref.load()
+    torch.set_num_threads(1)
+    a, b = job
+    t0 = time.perf_counter()
+    ref.xcorrvol_cpu(a, b, D, BS)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(pattern_lcn_cpu, frames_lcn_cpu):
+    """The reference CPU path on a bounded sample of the same workload: (a) one frame through the
+    reference's own xcorrvol_cpu (oracle/_ref, built from /root/reference by oracle/build_ref.py; else the C port) on
+    one core -- what one reference call does, its loop is serial (ext_cpu.cpp:7-12) -- and (b) one frame per host core
+    in `cores` independent processes, the fair all-cores number."""
+    import torch
     try:
         from oracle import build_ref
         ref = build_ref.load()
     except Exception:
         ref = None
-    a = frame_lcn_cpu.contiguous()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    a = frames_lcn_cpu[0].contiguous()
     b = pattern_lcn_cpu.contiguous()
     t0 = time.perf_counter()
     if ref is not None:
@@ -60,9 +142,30 @@ def cpu_baseline(pattern_lcn_cpu, frame_lcn_cpu):
         oracle.xcorrvol(a.numpy(), b.numpy(), D, BS, nthreads=1)
         kind = "port"
     dt = time.perf_counter() - t0
-    return {"value": H * W * D / dt / 1e6, "unit": "Mpix*disp/s", "cores": 1, "kind": kind,
-            "sample": "1 of the 16 frames of one step, full 512x432x128 NCC volume (xcorrvol_cpu, serial loop), "
-                      "%.1f s" % dt}
+    out = {"value": H * W * D / dt / 1e6, "unit": "Mpix*disp/s", "cores": 1, "kind": kind, "cpu_model": model,
+           "host_cores": ncpu,
+           "sample": "1 of the 16 frames of one step, full 512x432x128 NCC volume (xcorrvol_cpu, serial loop), %.1f s" % dt}
+    # (b) all host cores: one frame per process, at most 16 processes (about the same wall time as leg (a))
+    try:
+        import multiprocessing as mp
+        workers = max(1, min(ncpu, 16))
+        jobs = [(frames_lcn_cpu[i % frames_lcn_cpu.shape[0]].contiguous(), b) for i in range(workers)]
+        ctx = mp.get_context("spawn")
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            if ref is not None:
+                times = pool.map(_ref_xcorrvol_worker, jobs)
+            else:
+                times = None
+        wall = time.perf_counter() - t0
+        if times:
+            busy = max(times)                                  # processes run side by side: the slowest one bounds the rate
+            out["all_cores"] = {"value": workers * H * W * D / busy / 1e6, "unit": "Mpix*disp/s", "cores": workers,
+                                "sample": "%d processes x 1 frame each, slowest %.1f s (pool wall %.1f s incl. start-up)"
+                                          % (workers, busy, wall)}
+    except Exception as e:                                     # the single-core leg stands on its own
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def measured_traffic(kernel_substr):
@@ -80,29 +183,28 @@ def measured_traffic(kernel_substr):
 
 
 def parity_probe(te, device):
-    """disparity MAE vs the reference on the committed full-size golden (seeds 1234 / 42)."""
+    """disparity MAE vs the reference on the committed full-size golden (seeds 1234 / 42); runs BEFORE the warm-up."""
     try:
+        import numpy as np
+        import torch
         from tests import workloads
         from tests.util import golden
         g = golden("xcorrvol_cfg1")
         a = torch.from_numpy(workloads.uniform_frame(1234, H, W)).to(device)
         b = torch.from_numpy(workloads.uniform_frame(42, H, W)).to(device)
-        idx, _ = te.xcorrvol_argmax(a, b, D, BS)
+        idx, _, _ = te.xcorrvol_argmax(a, b, D, BS, return_volume=True)
         return float(np.abs(idx.cpu().numpy().astype(np.int64) - g["uni_argmax"].astype(np.int64)).mean())
-    except Exception as e:           # golden fixtures not shipped
+    except Exception:                # golden fixtures not shipped
         return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step (BASELINE config 2: 16)")
-    ap.add_argument("--algo", default="fast", choices=["fast", "exact"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,18 +223,40 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    workload = args.workload or ("config2" if world == 1 else "config3")
 
     os.environ["CTD_NCC_ALGO"] = args.algo
-    from connecting_the_dots_amd import _lib, torchext as te
+    from connecting_the_dots_amd import _lib, sharding, torchext as te
     L = _lib.lib()
 
     frames, pattern = make_inputs(args.frames, rank, device)
     pat_lcn, _ = te.lcn(pattern, LCN_RADIUS, LCN_EPS)        # once per run, as exp_synph.py:64-71 does
     pat_lcn = pat_lcn[0].contiguous()
+    mae = None if args.no_parity_probe or rank != 0 else parity_probe(te, device)
 
-    def step():
+    geo = None
+    if workload == "config3":
+        K = torch.tensor([[FOCAL, 0, 324.7], [0, 570.2, 250.1], [0, 0, 1]], device=device)
+        Ki = torch.linalg.inv(K.double()).float()
+        geo = te.ProjectionDepthSimilarityLoss(K, Ki, H, W, clamp=0.1)
+        R, t = make_poses(args.frames, rank, device)
+        half = args.frames // 2                                 # pairs (i, i + half): both halves are contiguous slices
+        Ra, ta, Rb, tb = R[:half].contiguous(), t[:half].contiguous(), R[half:2 * half].contiguous(), t[half:2 * half].contiguous()
+    losses = []
+
+    def step(exchange=True):
         x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
         idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D, BS, return_volume=True)
+        if geo is not None:
+            # disparity -> depth (+1: disparity 0 would be depth 1e12) and the symmetric geometric loss of the frame
+            # pairs (i, i + frames/2); then the path's only exchange: every rank's loss scalar to every rank
+            depth = te.idx_to_depth(idx, FOCAL * BASELINE_M, 1.0).view(-1, 1, H, W)
+            loss = geo(depth[:half], depth[half:2 * half], Ra, ta, Rb, tb)
+            if exchange:
+                losses.append(sharding.gather_scalars(loss) if backend == "nccl" or dist is None
+                              else sharding.gather_scalars(loss.cpu()))
+                if len(losses) > 4:
+                    losses.pop(0)
         return x, idx, vol
 
     def barrier():
@@ -144,11 +268,12 @@ def main():
     # Settle first (not part of the W warm-up steps the contract asks for, and just as untimed): on a freshly booted
     # box the first passes through the Python / allocator / code-object paths can take several ms of HOST time per
     # step while the image pages in; run until two consecutive synchronised steps agree, at most 16 extra steps.
+    # (No collective in here: the number of settle steps differs from rank to rank.)
     import gc
     prev = None
     for _ in range(16):
         t_s = time.perf_counter()
-        step()
+        step(exchange=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t_s
         if prev is not None and abs(dt - prev) <= 0.15 * min(dt, prev):
@@ -171,16 +296,23 @@ def main():
     avg_ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n_launch = L.ctd_kernel_timing_collect(ctypes.byref(avg_ms), ctypes.byref(cols))
 
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ranks_seen = dist.get_world_size()
 
     if rank == 0:
         units_per_step = world * args.frames * H * W * D
         value = units_per_step * args.steps / elapsed / 1e6
         kernel_units = args.frames * H * cols.value * D
         achieved = kernel_units * BYTES_PER_PIXDISP / (avg_ms.value * 1e-3) / 1e9 if n_launch else None
+        kernel = "ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel"
+        what = ("BASELINE config 2: batch=16 512x432 frames per GPU, 128 disparities, block 9, LCN(r=5,eps=0.05) + NCC "
+                "cost volume (materialised) + argmax") if workload == "config2" else (
+                "BASELINE config 3: 16 frames per GPU (%d in all), LCN + NCC cost volume (materialised) + argmax + "
+                "disparity->depth + two-view geometric loss on frame pairs + all-gather of the loss scalar" % (world * args.frames))
         out = {
             "metric": "Mpix*disparities/s on 512x432x128 cost volume; disparity MAE vs ref",
             "value": value,
@@ -194,23 +326,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: batch=16 512x432 frames per GPU, 128 disparities, block 9, "
-                                   "LCN(r=5,eps=0.05) + NCC cost volume (materialised) + argmax, algo=%s" % args.algo,
+            "config": {"workload": what + ", algo=%s" % args.algo,
                        "frames_per_gpu": args.frames, "H": H, "W": W, "D": D, "block_size": BS,
-                       "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
-            "disparity_mae_vs_ref": parity_probe(te, device),
+                       "parallelism": "frames sharded over %d GPU(s), one process per GPU%s" % (
+                           world, "" if world == 1 else ", one all-gather of a scalar per step (%s)" % (
+                               "RCCL" if backend == "nccl" else backend)),
+                       "ranks_seen": ranks_seen, "device": torch.cuda.get_device_name(device)},
+            "disparity_mae_vs_ref": mae,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel",
+                "kernel": kernel + (" (ranking the scores in its epilogue)" if args.algo == "fast" else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "avg_launch_ms": avg_ms.value, "launches": n_launch,
                 "algorithmic_bytes_per_launch": kernel_units * BYTES_PER_PIXDISP,
-                "traffic": measured_traffic("ncc_fast_t256_kernel" if args.algo == "fast" else "ncc_exact_kernel"),
+                "traffic": measured_traffic(kernel),
             },
         }
+        if geo is not None and losses:
+            out["config"]["loss_allgather"] = [float(v) for v in losses[-1].flatten().tolist()]
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[0].cpu())
+            out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[:min(args.frames, 32)].cpu())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -13,6 +13,7 @@
 // in which a whole wavefront (lane <-> disparity) re-scores each remaining pixel.
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
+#include "ctd_rank.h"
 
 
 namespace ctd {
@@ -98,40 +99,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // Merge of the per-group partials written by the volume kernel's in-kernel ranking (ncc_fast.hip, t256_consume):
 // 4 adjacent pixels per thread, one 16-byte load per disparity group.  A partial is the group's top score with
 // mantissa bits 0-3 = 15 - (disparity within the group) -- so the maximum carries its index -- and bit 4 = "the
-// group's runner-up lies within the re-ranking margin of its top".  A listed fully clamped run contributes its exact
-// value (run_vals) as one more candidate at its first disparity.  A pixel whose runner-up (another group's top, the
-// flagged in-group one, the run value) lies within the margin of its best goes to the resolve pass (work list); so
-// does one whose patched scores did not fit the patch list (dirty byte set by the fix-up pass).  The dirty bytes are
-// rewritten as "is on the work list" flags for rank_patch_check_kernel.
-__device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }   // as in ncc_fast.hip
-
-// Appends `item` to a work list for the lanes with `take` set: one atomic per wavefront (thousands of lanes bumping
-// one counter one by one cost the merge kernel as much as its memory traffic).
-__device__ inline void worklist_push(bool take, int64_t item, unsigned* __restrict__ counter, int64_t* __restrict__ list) {
-  const unsigned long long m = __ballot(take);
-  if (m == 0) return;                                          // wave-uniform
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-  unsigned base = 0;
-  if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-  base = __shfl(base, leader);
-  if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = item;
-}
-
+// group's runner-up lies within the re-ranking margin of its top".  A pixel whose runner-up (another group's top or
+// the flagged in-group one) lies within the margin of its best goes to the resolve pass (work list); its flag byte
+// says so.  Scores of listed windows (NaN in the volume kernel) are not in here: ncc_fast_fixup_ranked holds each of
+// them against the merged best afterwards and extends the work list.
 __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, int n_dg, int dg_size,
-                                                         const float* __restrict__ run_flag,
-                                                         long run_flag_frame_stride, long run_flag_row_stride,
-                                                         const float* __restrict__ run_vals,
-                                                         unsigned char* __restrict__ dirty,
-                                                         int64_t* __restrict__ idx, float* __restrict__ best, int D,
-                                                         int H, int W, int tail, float eps, long total_quads,
-                                                         unsigned* __restrict__ n_hard, int64_t* __restrict__ hard_list) {
+                                                         unsigned char* __restrict__ flags,
+                                                         int64_t* __restrict__ idx, float* __restrict__ best, long HW,
+                                                         float eps, long total_quads, unsigned* __restrict__ n_hard,
+                                                         int64_t* __restrict__ hard_list) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_quads) return;
-  const long HW = (long)H * W;
   const long p0 = t * 4;
   const long f = p0 / HW, q0 = p0 - f * HW;
-  const int h = (int)(q0 / W), w0 = (int)(q0 - (long)h * W);
   const float* a0 = k0 + f * n_dg * HW + q0;
   float M[4], R[4];
   int gi[4];
@@ -154,62 +135,21 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
       }
     }
   }
-  const float rf = w0 + tail < D ? run_flag[f * run_flag_frame_stride + h * run_flag_row_stride] : 0.f;
-  const bool run_listed = rf != rf;                            // NaN deviation: the run's window is listed
   f4 bq;
-  const unsigned dirty4 = *(const unsigned*)(dirty + p0);
   unsigned listed4 = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int w = w0 + k;
-    int d = gi[k] * dg_size + 15 - (__float_as_int(M[k]) & 15);
-    float b = __int_as_float((__float_as_int(M[k]) & ~31) | 16);  // centre of the truncation interval
-    float m = M[k], r = R[k];
-    bool close = (__float_as_int(M[k]) & 16) != 0;              // in-group runner-up within the margin (volume kernel)
-    if (run_listed && w + tail < D) {
-      const float c = run_vals[(f * H + h) * D + w + tail];
-      if (c == c) {                                             // not NaN: the run's exact score competes at its first disparity
-        if (c > m) { r = m; m = c; b = c; d = w + tail; close = false; }
-        else r = fmaxf(r, c);
-      }
-    }
+    const float m = M[k];
+    const bool close = (__float_as_int(m) & 16) != 0;           // in-group runner-up within the margin (volume kernel)
     // m == -inf: every score of the pixel was left to the fix-up pass
-    const bool hard = eps >= 0.f && (((dirty4 >> (8 * k)) & 0xff) != 0 || close || r >= m - rank_margin(eps, m) ||
-                                     !(m > -INFINITY));
-    idx[p0 + k] = d;
-    bq[k] = b;
+    const bool hard = eps >= 0.f && (close || R[k] >= m - rank_margin(eps, m) || !(m > -INFINITY));
+    idx[p0 + k] = gi[k] * dg_size + 15 - (__float_as_int(m) & 15);
+    bq[k] = __int_as_float((__float_as_int(m) & ~31) | 16);     // centre of the truncation interval
     worklist_push(hard, p0 + k, n_hard, hard_list);
     if (hard) listed4 |= 1u << (8 * k);
   }
-  *(unsigned*)(dirty + p0) = listed4;
+  *(unsigned*)(flags + p0) = listed4;
   *(f4*)(best + p0) = bq;
-}
-
-// Scores the fix-up pass recomputed (listed windows) were NaN for the in-kernel ranking.  A pixel whose merged best
-// is not clear of such a score by the margin joins the work list (once: its flag byte is claimed atomically).
-__global__ __launch_bounds__(256) void rank_patch_check_kernel(const unsigned* __restrict__ n_patches,
-                                                               const unsigned long long* __restrict__ patches,
-                                                               unsigned capacity, const float* __restrict__ best,
-                                                               unsigned* __restrict__ flags, float eps,
-                                                               unsigned* __restrict__ n_hard,
-                                                               int64_t* __restrict__ hard_list) {
-  const unsigned n = min(*n_patches, capacity);
-  const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += stride) {      // whole wavefronts stay in the loop
-    const unsigned i = i0 + threadIdx.x;
-    bool take = false;
-    unsigned pix = 0;
-    if (i < n) {
-      const unsigned long long e = patches[i];
-      pix = (unsigned)(e >> 32);
-      const float val = __int_as_float((int)(unsigned)e), m = best[pix];
-      if (!(val < m - rank_margin(eps, m))) {                 // also NaN
-        const unsigned bit = 1u << (8 * (pix & 3));
-        take = (atomicOr(flags + (pix >> 2), bit) & bit) == 0;
-      }
-    }
-    worklist_push(take, pix, n_hard, hard_list);
-  }
 }
 
 // Pass 2: one wavefront per pixel of the work list.  VOL: lane <-> disparity collects the pixel's candidate set from
@@ -375,22 +315,22 @@ static int launch_resolve(const float* vol, const float* in0, const float* in1, 
   return CTD_OK;
 }
 
-int rank_merge_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
-                   int64_t* idx, float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream) {
-  if (D > kMaskWords * 64 || W % 4 != 0) return CTD_ERR_UNSUPPORTED;
+int rank_merge_f32(const RankPlan& rp, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream) {
+  if (D > kMaskWords * 64 || W % 4 != 0 || !best) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
-  float* scratch_best = best ? best : rp.best_scratch;
-  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0,
-                     rp.n_dg, rp.dg_size, rp.run_flag, rp.run_flag_frame_stride, rp.run_flag_row_stride, rp.run_vals,
-                     rp.dirty, idx, scratch_best, D, H, W, bs - 1 - bs / 2, eps, total / 4, rp.n_hard, rp.hard_list);
+  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0, rp.n_dg,
+                     rp.dg_size, rp.flags, idx, best, (long)H * W, rp.eps, total / 4, rp.n_hard, rp.hard_list);
   CTD_LAUNCH_CHECK();
-  if (eps < 0.f) return CTD_OK;                            // nothing is listed: plain argmax of the fast scores
-  hipLaunchKernelGGL(rank_patch_check_kernel, dim3(512), dim3(256), 0, stream, rp.n_patches, rp.patches, rp.patch_capacity,
-                     scratch_best, (unsigned*)rp.dirty, eps, rp.n_hard, rp.hard_list);
-  CTD_LAUNCH_CHECK();
-  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, rp.n_hard,
+  return CTD_OK;
+}
+
+int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                     int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
+  if (rp.eps < 0.f) return CTD_OK;                         // nothing is listed: plain argmax of the fast scores
+  const long total = (long)frames * H * W;
+  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.n_hard,
                                     rp.hard_list, stream)
-             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, rp.n_hard,
+             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.n_hard,
                                      rp.hard_list, stream);
 }
 

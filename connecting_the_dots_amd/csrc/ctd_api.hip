@@ -158,11 +158,16 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
       // ranked inside the volume kernel: partial top-2 per disparity group, merged here; no pass over the volume
       RankPlan rp;
       rp.eps = rerank_eps;
+      const hipStream_t hs = (hipStream_t)stream;
       int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
-                            workspace_bytes, &rp, (hipStream_t)stream);
+                            workspace_bytes, &rp, hs);                 // pre-pass + volume kernel (writes the partials)
       if (st) return st;
-      return rank_merge_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
-                            (hipStream_t)stream);
+      float* b = best ? best : rp.best_scratch;
+      st = rank_merge_f32(rp, idx, b, frames, D, H, W, hs);
+      if (st) return st;
+      st = ncc_fast_fixup_ranked(in0, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, b, hs);
+      if (st) return st;
+      return rank_resolve_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, hs);
     }
     if (!vol_out) return CTD_ERR_INVALID_ARG;                              // this shape ranks a materialised volume
     int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
@@ -304,6 +309,16 @@ int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bas
   DeviceGuard g(device);
   if (g.status) return g.status;
   return disp_to_depth_fwd_f32(disp, depth, n, baseline_focal, (hipStream_t)stream);
+}
+
+int ctd_idx_to_depth_f32(const int64_t* idx, float* depth, long n, float baseline_focal, float disp_offset, int device,
+                         void* stream) {
+  if (n < 0) return CTD_ERR_INVALID_ARG;
+  if (n == 0) return CTD_OK;
+  if (!idx || !depth) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return idx_to_depth_f32(idx, depth, n, baseline_focal, disp_offset, (hipStream_t)stream);
 }
 
 int ctd_disp_to_depth_bwd_f32(const float* disp, const float* grad_depth, float* grad_disp, long n,

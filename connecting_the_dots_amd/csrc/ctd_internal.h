@@ -27,17 +27,10 @@ struct RankPlan {
   float* k0;                  // [frames][n_dg][H][W] top score KEY of every disparity group: the f32 score with mantissa
                               // bits 0-3 = 15 - d % dg_size and bit 4 = "group's runner-up within the margin of its top"
   int n_dg, dg_size;          // disparity groups, disparities per group
-  unsigned char* dirty;       // [frames][H][W] in: 1 = a patched score of this pixel did not fit the patch list;
-                              // out (rank_merge_kernel): 1 = pixel is on the work list
-  const unsigned* n_patches;  // scores recomputed by the fix-up pass outside the runs: (flat pixel << 32 | f32 bits)
-  const unsigned long long* patches;
-  unsigned patch_capacity;
-  float* best_scratch;        // [frames][H][W] merged best score when the caller does not ask for it
+  unsigned char* flags;       // [frames][H][W] 1 = pixel is on the work list (written by rank_merge_kernel)
   unsigned* n_hard;           // work list of the pixels the exact re-scoring has to settle
   int64_t* hard_list;
-  const float* run_flag;      // pattern deviation plane at the fully clamped run's window column: sign bit = listed
-  long run_flag_frame_stride, run_flag_row_stride;
-  const float* run_vals;      // [frames][H][D] exact score of a listed run, indexed by its first disparity
+  float* best_scratch;        // [frames][H][W] merged best score when the caller does not ask for it
   size_t bytes;               // workspace bytes up to the end of these buffers
 };
 size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
@@ -46,13 +39,16 @@ size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_f
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off);
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream);
+int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,
+                          int D, int bs, void* workspace, const RankPlan& rank, const float* best, hipStream_t stream);
 
 // argmax_rerank.hip
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
                       size_t workspace_bytes, bool counter_cleared, hipStream_t stream);
-int rank_merge_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
-                   int64_t* idx, float* best, int frames, int D, int H, int W, int bs, float eps, hipStream_t stream);
+int rank_merge_f32(const RankPlan& rp, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream);
+int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                     int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream);
 
 // photometric.hip
 int photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,
@@ -97,6 +93,7 @@ int lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, 
 
 // losses.hip
 int disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bf, hipStream_t s);
+int idx_to_depth_f32(const int64_t* idx, float* depth, long n, float bf, float offset, hipStream_t s);
 int disp_to_depth_bwd_f32(const float* disp, const float* go, float* gi, long n, float bf, hipStream_t s);
 size_t disparity_loss_workspace_bytes(int B, int H, int W);
 int disparity_loss_fwd_f32(const float* disp, const float* edge, float* loss, int B, int H, int W, void* ws,

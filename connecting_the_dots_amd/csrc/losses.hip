@@ -70,6 +70,20 @@ __global__ void d2d_bwd_kernel(const float* __restrict__ disp, const float* __re
   }
 }
 
+// same with the disparity given as the int64 argmax index plus a constant (disparity 0 would be depth 1e12)
+__global__ void d2d_idx_kernel(const int64_t* __restrict__ idx, float* __restrict__ depth, long n, float bf, float offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = fmaxf((float)idx[i] + offset, 0.f) + 1e-12f;
+    depth[i] = (1.0f / x) * bf;
+  }
+}
+int idx_to_depth_f32(const int64_t* idx, float* depth, long n, float bf, float offset, hipStream_t s) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(d2d_idx_kernel, dim3(blocks), dim3(256), 0, s, idx, depth, n, bf, offset);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
 int disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bf, hipStream_t s) {
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(d2d_fwd_kernel, dim3(blocks), dim3(256), 0, s, disp, depth, n, bf);

@@ -31,6 +31,7 @@
 
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
+#include "ctd_rank.h"
 
 
 namespace ctd {
@@ -70,7 +71,6 @@ struct PrepassJob {
   int col_lo, col_hi;
   unsigned* n_runs;
   unsigned long long* run_rows;
-  unsigned char* dirty;       // job a only, may be null: per-pixel flag byte of the ranking passes, cleared here
 };
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   unsigned long long* __restrict__ flag_list = jp.flag_list;
   unsigned* __restrict__ n_runs = jp.n_runs;
   unsigned long long* __restrict__ run_rows = jp.run_rows;
-  unsigned char* __restrict__ dirty = jp.dirty;
   if ((int)blockIdx.x * kSTW >= W_out) return;
   extern __shared__ double lds_d[];
   __shared__ double cred[kSTW * kSRows];
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     out_mean[o] = (float)mc;
     out_dev[o] = listed ? __int_as_float(0x7fc00000) : rdev;
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
-    if (dirty && col >= 0 && col < W) dirty[((long)img_idx * H + h) * W + col] = 0;
     if (listed && col >= col_lo && col < col_hi) {
       flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)img_idx << 40) | ((unsigned long long)h << 20) |
                                          (unsigned long long)(col + 0x80000);
@@ -213,9 +211,10 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
 //                             whole run d' >= d of pixel w = x + d (ext.h:152-154 makes the run constant).
 // The NCC is symmetric in the two windows (dot and sigma0*sigma1 commute exactly), so one staging layout
 // serves both cases.
-// Ranked calls (ncc_fast_f32 with a RankPlan): every recomputed score outside the runs is also appended to
-// `patches` as (flat pixel index, score) for rank_patch_check_kernel; when the list is full the pixel's dirty byte is
-// set instead (rank_merge_kernel then hands the pixel to the exact re-scoring).  `out` may be null then.
+// Ranked calls (ncc_fast_fixup_ranked, after rank_merge_kernel): the in-kernel ranking never saw these scores (NaN),
+// so every recomputed one is held against the pixel's merged best; a pixel whose best is not clear of it by the
+// re-ranking margin joins the work list of the exact re-scoring (once: its flag byte is claimed atomically).  `out`
+// may be null then (nothing was materialised).
 constexpr int kFixupBlocks = 2048;
 
 // Loops over the window rows stay rolled (a fully unrolled body is ~40 KB of straight-line code that every
@@ -230,11 +229,10 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
                                                         const unsigned long long* __restrict__ list_a,
                                                         const unsigned long long* __restrict__ list_b,
                                                         float* __restrict__ run_vals,
-                                                        unsigned char* __restrict__ dirty,
-                                                        unsigned* __restrict__ n_patches,
-                                                        unsigned long long* __restrict__ patches,
-                                                        unsigned patch_capacity, int frames, int C, int H, int W,
-                                                        int D, int bs_rt) {
+                                                        const float* __restrict__ best, float rank_eps,
+                                                        unsigned* __restrict__ flags, unsigned* __restrict__ n_hard,
+                                                        int64_t* __restrict__ hard_list, int frames, int C, int H,
+                                                        int W, int D, int bs_rt) {
   extern __shared__ float lds_fix[];
   const int bs = BS > 0 ? BS : bs_rt;
   const int lane = threadIdx.x & 63;
@@ -356,12 +354,15 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
         if (d < D) run_vals[((long)f * H + h) * D + d] = bad ? val : __int_as_float(0x7fc00000);
       } else if (bad) {
         if (out) out[((long)f * D + d) * HW + (long)h * W + w] = val;
-        if (patches) {                                       // the in-kernel ranking left this score out
-          const long pix = ((long)f * H + h) * W + w;
-          const unsigned slot = atomicAdd(n_patches, 1u);
-          if (slot < patch_capacity) patches[slot] = ((unsigned long long)pix << 32) | (unsigned)__float_as_int(val);
-          else dirty[pix] = 1;
+      }
+      if (best) {                                            // wave-uniform: ranked call
+        bool take = false;
+        const long pix = ((long)f * H + h) * W + w;
+        if (bad) {
+          const float m = best[pix];
+          if (!(val < m - rank_margin(rank_eps, m))) take = worklist_claim(flags, pix);   // (also a NaN best)
         }
+        worklist_push(take, pix, n_hard, hard_list);
       }
     }
   }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   const int seg = min(d - tail + 1, W);                    // pixels w in [0, d - tail]
   // the work-list counter of the ranking pass that may follow (argmax_rerank.hip) lives at the start of the
   // workspace, which the volume kernel is done with by now: cleared here instead of by a memset of its own
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *rank_counter = 0u;
+  if (rank_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *rank_counter = 0u;
   const unsigned n_r = counters[2];
   if (seg <= 0 || n_r == 0) return;
   if (tid == 0) s_n = 0;
@@ -1030,9 +1031,6 @@ constexpr int kRank = 1, kNoStore = 2;         // MODE bits of the tile-256 kern
 constexpr int kTRankBufs = 3;
 constexpr int kTRankFloats = kTRankBufs * kTRows * 2 * 256;   // [chunk % 3][row][top | second][column-in-quad][lane]
 
-// margin inside which two scores count as tied for the exact re-scoring: the caller's eps plus the truncation of two
-// keys (5 mantissa bits each: tag + flag); the same expression in the volume kernel and in rank_merge_kernel
-__device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }
 
 __device__ inline float rank_key(float v, int tag) {          // tag = 15 - disparity within the group
   return __int_as_float((__float_as_int(v) & ~15) | tag);
@@ -1530,30 +1528,26 @@ bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs) {
 // ranking buffers behind the volume pass's workspace
 static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, int D) {
   RankPlan rp;
+  rp.eps = 0.f;
   rp.n_dg = ceil_div(D, kTDG);
   rp.dg_size = kTDG;
   const size_t npart = align_up((size_t)frames * rp.n_dg * H * W * sizeof(float), 256);
-  const size_t ndirty = align_up((size_t)frames * H * W, 256);
+  const size_t nflag = align_up((size_t)frames * H * W, 256);
   const size_t nlist = align_up((size_t)frames * H * W * sizeof(int64_t), 256);
   char* p = (char*)base + offset;
   rp.k0 = (float*)p;
-  rp.dirty = (unsigned char*)(p + npart);
-  rp.n_hard = (unsigned*)(p + npart + ndirty);
-  rp.hard_list = (int64_t*)(p + npart + ndirty + 256);
-  rp.patches = (const unsigned long long*)(p + npart + ndirty + 256 + nlist);
-  rp.patch_capacity = (unsigned)((size_t)frames * H * W);
-  rp.n_patches = nullptr;
-  rp.best_scratch = (float*)(p + npart + ndirty + 256 + 2 * nlist);
-  rp.bytes = offset + npart + ndirty + 256 + 2 * nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
-  rp.run_flag = nullptr; rp.run_flag_frame_stride = 0; rp.run_flag_row_stride = 0; rp.run_vals = nullptr;
-  rp.eps = 0.f;
+  rp.flags = (unsigned char*)(p + npart);
+  rp.hard_list = (int64_t*)(p + npart + nflag);
+  rp.best_scratch = (float*)(p + npart + nflag + nlist);
+  rp.n_hard = nullptr;                                             // lives with the volume pass's counters
+  rp.bytes = offset + npart + nflag + nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
   return rp;
 }
 
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off) {
-  const size_t base = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern).bytes;
-  const RankPlan rp = rank_plan(nullptr, base, frames, H, W, D);
-  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.dirty; off[2] = (size_t)rp.n_hard; off[3] = (size_t)rp.hard_list;
+  const FastWorkspace ws = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern);
+  const RankPlan rp = rank_plan(nullptr, ws.bytes, frames, H, W, D);
+  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.flags; off[2] = (size_t)(ws.counters + 3); off[3] = (size_t)rp.hard_list;
   off[4] = (size_t)rp.n_dg;
 }
 
@@ -1654,9 +1648,36 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
   return CTD_OK;
 }
 
-// `rank` non-null: also rank every pixel's scores inside the volume kernel (see t256_consume) and fill *rank with
-// the buffers rank_merge_f32 (argmax_rerank.hip) needs; `out` may then be null (no volume is materialised).
-// rank->eps is an input: the re-ranking margin the partials are flagged against.
+static int launch_fixup(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
+                        int W, int D, int bs, const FastWorkspace& ws, bool per_frame, const RankPlan* rank, const float* best,
+                        unsigned* scan_counter, hipStream_t stream) {
+  // reference-order recomputation of the outputs of listed (ill-conditioned) windows; the grid drains
+  // immediately when nothing was listed
+  const size_t lds = sizeof(float) * 4 * (3 * (size_t)bs * bs + 2 * (size_t)bs * (bs + D - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  auto fix = bs == 9 ? ncc_fixup_kernel<9> : ncc_fixup_kernel<0>;
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
+                     ws.flag_a, ws.flag_b, ws.run_vals, rank && rank->eps >= 0.f ? best : nullptr, rank ? rank->eps : -1.f,
+                     rank ? (unsigned*)rank->flags : nullptr, rank ? rank->n_hard : nullptr,
+                     rank ? rank->hard_list : nullptr, frames, C, H, W, D, bs);
+  CTD_LAUNCH_CHECK();
+  if (!out) return CTD_OK;                                   // nothing to spread without a volume
+  const size_t lds_rows = sizeof(int) * (size_t)C * H;
+  if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
+  // (the old scan's work-list counter sits at the start of the workspace, which the volume kernel is done with by
+  // now: cleared by the runs kernel instead of by a memset of its own)
+  hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
+                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, scan_counter);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+// `rank` non-null: also rank every pixel's scores inside the volume kernel (see t256_consume), fill *rank with the
+// buffers the later passes need and STOP after the volume kernel -- the caller runs rank_merge_f32, then
+// ncc_fast_fixup_ranked (which needs the merged best scores), then rank_resolve_f32.  `out` may then be null (no
+// volume is materialised).  rank->eps is an input: the re-ranking margin the partials are flagged against.
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
@@ -1670,12 +1691,8 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
     const float eps = rank->eps;
     *rank = rank_plan(workspace, ws.bytes, frames, H, W, D);
     rank->eps = eps;
+    rank->n_hard = ws.counters + 3;                              // cleared with the other counters below
     need = rank->bytes;
-    rank->run_flag = ws.v1 + (-(bs - 1 - bs / 2) + ws.xoff);     // deviation plane at the run window's column
-    rank->run_flag_frame_stride = per_frame ? (long)C * H * ws.W1 : 0;
-    rank->run_flag_row_stride = ws.W1;
-    rank->run_vals = ws.run_vals;
-    rank->n_patches = ws.counters + 3;                           // cleared with the other counters below
   }
   if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
@@ -1683,9 +1700,9 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr, rank ? rank->dirty : nullptr};
+                         nullptr, nullptr};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, nullptr};
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows};
   int st = launch_prepass(ja, jb, H, W, bs, stream);
   if (st) return st;
   switch (bs) {
@@ -1695,32 +1712,18 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
     case 9: st = launch_fast<9>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;
     default: return CTD_ERR_UNSUPPORTED;
   }
-  if (st) return st;
-  // reference-order recomputation of the outputs of flagged (ill-conditioned) windows; the grid drains
-  // immediately when nothing was flagged
-  const size_t lds = sizeof(float) * 4 * (3 * (size_t)bs * bs + 2 * (size_t)bs * (bs + D - 1));
-  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
-  auto fix = bs == 9 ? ncc_fixup_kernel<9> : ncc_fixup_kernel<0>;
-  if (lds > 64 * 1024)
-    CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
-                     ws.flag_a, ws.flag_b, ws.run_vals, rank ? rank->dirty : nullptr, rank ? ws.counters + 3 : nullptr,
-                     rank ? (unsigned long long*)rank->patches : nullptr, rank ? rank->patch_capacity : 0u, frames, C, H, W,
-                     D, bs);
-  CTD_LAUNCH_CHECK();
-  // the work-list counter of the ranking pass that follows is cleared by the runs kernel (no memset of its own):
-  // the old scan keeps it at the start of the workspace, which the volume kernel is done with by now
-  unsigned* counter = rank ? rank->n_hard : (unsigned*)workspace;
-  if (!out) {                                                // nothing to spread without a volume
-    CTD_HIP_TRY(hipMemsetAsync(counter, 0, 16, stream));
-    return CTD_OK;
-  }
-  const size_t lds_rows = sizeof(int) * (size_t)C * H;
-  if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
-                     ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, counter);
-  CTD_LAUNCH_CHECK();
-  return CTD_OK;
+  if (st || rank) return st;
+  return launch_fixup(in0, in1, in1_frame_stride, out, frames, C, H, W, D, bs, ws, per_frame, nullptr, nullptr,
+                      (unsigned*)workspace, stream);
+}
+
+// Second half of a ranked call, after rank_merge_f32: fix-up of the listed windows (volume patch when there is one,
+// run values) with every recomputed score held against the merged `best` of its pixel.
+int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,
+                          int D, int bs, void* workspace, const RankPlan& rank, const float* best, hipStream_t stream) {
+  const bool per_frame = in1_frame_stride != 0;
+  FastWorkspace ws = fast_workspace(workspace, frames, 1, H, W, D, per_frame);
+  return launch_fixup(in0, in1, in1_frame_stride, out, frames, 1, H, W, D, bs, ws, per_frame, &rank, best, nullptr, stream);
 }
 
 }  // namespace ctd

@@ -590,6 +590,18 @@ def disp_to_depth(disp, baseline_focal):
     return DispToDepthFunction.apply(disp, baseline_focal)
 
 
+def idx_to_depth(idx, baseline_focal, disp_offset=0.0):
+    """Additive: depth of the int64 disparity indices `xcorrvol_argmax` returns, `baseline_focal / (relu(idx +
+    disp_offset) + 1e-12)`, same shape as `idx` (f32).  Not differentiable."""
+    _check(idx, "idx", (torch.int64,))
+    depth = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+    dev = idx.device
+    st = _lib.lib().ctd_idx_to_depth_f32(_ptr(idx), _ptr(depth), idx.numel(), float(baseline_focal), float(disp_offset),
+                                         dev.index, _stream(dev))
+    _lib.check(st, "idx_to_depth")
+    return depth
+
+
 class DisparityLossFunction(torch.autograd.Function):
     """Sobel 5x5 + edge-aware disparity loss (networks.DisparityLoss.tforward, networks.py:395-412) -> scalar."""
 

@@ -189,6 +189,11 @@ int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float bas
                               int device, void* stream);
 int ctd_disp_to_depth_bwd_f32(const float* disp, const float* grad_depth, float* grad_disp, long n,
                               float baseline_focal, int device, void* stream);
+/* Same forward for a disparity given as the argmax index of ctd_xcorrvol_argmax_f32 (int64) plus a constant offset:
+ * depth = (baseline*focal) / (relu(float(idx) + disp_offset) + 1e-12).  Not differentiable (additive, no reference
+ * counterpart: saves the int64 -> float and offset passes between the matcher and the geometric loss). */
+int ctd_idx_to_depth_f32(const int64_t* idx, float* depth, long n, float baseline_focal, float disp_offset,
+                         int device, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * Edge-aware disparity loss: SobelFilter (5x5, replicate pad) + DisparityLoss.tforward,

@@ -23,7 +23,7 @@ off = (ctypes.c_size_t * 5)()
 L.ctd_xcorrvol_rank_layout(N, H, W, D, 0, off)
 n_hard = int(ws[off[2]:off[2] + 4].view(torch.int32).item())
 dirty = ws[off[1]:off[1] + N * H * W].view(N, H, W)
-print("pixels", N * H * W, "listed for re-scoring", n_hard, "dirty", int(dirty.sum()))
+print("pixels", N * H * W, "listed for re-scoring", n_hard, "flag bytes set", int(dirty.sum()))
 hl = ws[off[3]:off[3] + 8 * n_hard].view(torch.int64)
 w = (hl % W).cpu().numpy(); h = ((hl // W) % H).cpu().numpy()
 print("listed by column: w<124:", int((w < 124).sum()), " w>=124:", int((w >= 124).sum()))
