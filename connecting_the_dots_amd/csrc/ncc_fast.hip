@@ -56,7 +56,7 @@ constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
 constexpr double kDevFloor = 6e-3;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 3e-4 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
-// out_mean = window mean - cval, out_dev = 1 / sqrt(sum of squared deviations) (NaN: listed window), out_img = img - cval
+// out_mean = mean_scale * (window mean - cval), out_dev = 1 / sqrt(sum of squared deviations) (NaN: listed window), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
 // cval = f64 window mean at the image centre, recomputed identically by every workgroup.
 // One launch serves the frames (job a) and the pattern (job b): blockIdx.z < a.nimg -> image blockIdx.z of job a,
@@ -71,6 +71,8 @@ struct PrepassJob {
   int col_lo, col_hi;
   unsigned* n_runs;
   unsigned long long* run_rows;
+  double mean_scale;          // out_mean = mean_scale * (window mean - cval): -bs^2 for the frames (the kernels' n*ma*mb
+                              // term then needs no multiply of its own), 1 for the pattern
 };
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     const float rdev = (float)(1.0 / sqrt(var > 0 ? var : 1.0));  // reciprocal deviation (see ncc_inv_norm)
     const long o = ((long)img_idx * H + h) * W_out + xi;
     const int col = xi + x_start;
-    out_mean[o] = (float)mc;
+    out_mean[o] = (float)(jp.mean_scale * mc);
     out_dev[o] = listed ? __int_as_float(0x7fc00000) : rdev;
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     if (listed && col >= col_lo && col < col_hi) {
@@ -438,10 +440,10 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
 }
 
 // 1 / (sa * sb + 1e-8) from the RECIPROCAL deviations the pre-pass stores: t = ra * rb, times (1 - 1e-8 t), the
-// first two terms of 1 / (1 + 1e-8 t).  Three full-rate instructions (+ the multiply by cov) instead of an fma, a
-// quarter-rate v_rcp_f32 and a multiply: the consumer loops are VALU-bound and the reciprocal was a fifth of their
-// issue slots.  The neglected terms are (1e-8 t)^2 relative: below 1e-7 because the pre-pass lists every window whose
-// deviation is under kDevFloor (t <= 1 / kDevFloor^2), and listed windows go through the fix-up pass.
+// first two terms of 1 / (1 + 1e-8 t): three full-rate instructions instead of an fma, a quarter-rate v_rcp_f32
+// (9.3 cycles per wave against 2.7 for a 4-byte VOP2 and 4.2 for an 8-byte VOP3, tools/ubench.hip) and a multiply.
+// The neglected terms are (1e-8 t)^2 relative: below 1e-7 because the pre-pass lists every window whose deviation is
+// under kDevFloor (t <= 1 / kDevFloor^2), and listed windows go through the fix-up pass.
 __device__ inline float ncc_inv_norm(float ra, float rb) {
   const float t = ra * rb;
   return t * fmaf(t, -1e-8f, 1.f);
@@ -596,7 +598,6 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
   const int w0 = w_lo - HALF + lane;           // unclamped product column == output column
   float* vol = out + (long)f * D * HW;
   const bool lane_out = (lane >= HALF) && (lane < 64 - TAIL) && (w0 < W);
-  const float nf = (float)(BS * BS);
   const int bq = lane + (kFDG - 1) - wave * kFND;   // span slot of (lane, j = 0); j-th disparity reads bq - j
 
   float P[kFND][BS == 9 ? 2 : BS - 1];
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
       }
       const int h = r - TAIL;                                     // output row completed by product row r
       const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
-      const float nma = -nf * mav;
+      const float nma = mav;                                      // -bs^2 * (window mean), from the pre-pass
 #pragma unroll
       for (int j = 0; j < kFND; ++j) {
         const float p = a * bv[j];
@@ -756,7 +757,6 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
   const int c0 = c_lo + kWCols * lane;         // unclamped first column of this lane
   float* vol = out + (long)f * D * HW;
   const bool lane_out = (lane >= 1) && (lane <= 62) && (c0 < W);
-  const float nf = (float)(BS * BS);
 
   float P[kWND][kWCols][BS == 9 ? 2 : BS - 1];
   float T[kWND][kWCols][BS == 9 ? 6 : 1];
@@ -804,7 +804,7 @@ __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict
       const RowOps cur = load_row(lds + ((chunk % kWBufs) * kWRows + (u % kWRows)) * kWPack);
       float nma[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nma[i] = -nf * cur.ma[i];
+      for (int i = 0; i < 4; ++i) nma[i] = cur.ma[i];              // -bs^2 * (window mean), from the pre-pass
       const int h = r - TAIL;
       const bool row_out = (h >= h_lo) && (h < h_hi);             // wave-uniform
 #pragma unroll
@@ -1058,7 +1058,7 @@ template <bool ACCUM, int MODE, int KS>
 __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0, float rank_eps,
                                              int WAVE, int f, int dg, int lane, int w_lo, int h_lo, int h_hi,
                                              int r_begin, int n_iters, int H, int W, int D) {
-  constexpr int BS = 9, TAIL = 4, STEP = lcm_ce(6, kTRows);
+  constexpr int TAIL = 4, STEP = lcm_ce(6, kTRows);               // block size 9
   constexpr bool RANK = (MODE & kRank) != 0, STORE = (MODE & kNoStore) == 0;
   const long HW = (long)H * W;
   const int d_base = dg * kTDG + WAVE * kTND;
@@ -1067,7 +1067,6 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
   const unsigned l4 = 4u * (unsigned)lane;                         // first column of the lane, relative to w_lo
   float* vol = out + (long)f * D * HW + w_lo;
   const bool lane_out = w_lo + (int)l4 < W;
-  const float nf = (float)(BS * BS);
   float P[kTND][4][2], T[kTND][4][6];
 #pragma unroll
   for (int j = 0; j < kTND; ++j)
@@ -1251,7 +1250,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float sh = fmaf(halo_mask, hq[i], sj[i]);
-            const float cov = fmaf(-nf * qma[i], me[kS + (1 - j) + i], sh);
+            const float cov = fmaf(qma[i], me[kS + (1 - j) + i], sh);   // qma = -bs^2 * (window mean), from the pre-pass
             val[i] = cov * ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
           }
           const int d = d_base + j;
@@ -1700,9 +1699,9 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr};
+                         nullptr, nullptr, -(double)(bs * bs)};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows};
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0};
   int st = launch_prepass(ja, jb, H, W, bs, stream);
   if (st) return st;
   switch (bs) {

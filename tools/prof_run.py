@@ -1,5 +1,6 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-"""Runs one hot-path kernel family a few times (profiling target for rocprofv3 --pmc passes)."""
+"""Runs one hot-path kernel family a few times (profiling target for rocprofv3 --pmc passes):
+    python tools/prof_run.py [fast|exact|rank] [frames]      (rank = fast volume kernel with the in-kernel ranking)"""
 import sys, torch
 from connecting_the_dots_amd import torchext as te
 algo = sys.argv[1] if len(sys.argv) > 1 else "fast"
@@ -9,5 +10,8 @@ torch.manual_seed(0)
 a = torch.rand(N, 1, H, W, device="cuda"); b = torch.rand(1, 1, H, W, device="cuda")
 a, _ = te.lcn(a, 5, 0.05); b, _ = te.lcn(b, 5, 0.05); b = b[0].contiguous()
 for _ in range(3):
-    v = te.xcorrvol_batch(a, b, D, 9, algo=algo)
+    if algo == "rank":
+        v = te.xcorrvol_argmax(a, b, D, 9, return_volume=True, algo="fast")
+    else:
+        v = te.xcorrvol_batch(a, b, D, 9, algo=algo)
 torch.cuda.synchronize()
