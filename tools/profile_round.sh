@@ -1,28 +1,74 @@
 #!/bin/bash
-# Collects the judged profile artefacts of one round into gpurun_out/profiles_<tag>/ (copy to profiles/ afterwards).
-tag=${1:-round1}
+# Collects the judged profile artefacts of one round into gpurun_out/profiles_<tag>/ (copy to profiles/ afterwards):
+#   <tag>_bench_kernel_stats.csv   per-kernel statistics of `python bench.py` from the rocprofv3 kernel trace, counting
+#                                   only each kernel's DOMINANT launch shape (the 16-frame launches of the timed steps;
+#                                   set-up launches such as the one-image LCN of the pattern have another grid)
+#   <tag>_pmc_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE (KiB) per launch of the same launches, separate --pmc passes
+#   <tag>_bench_under_rocprof.json the bench line of the traced run
+# bench.py runs with --no-parity-probe: the probe's 1-frame launches of the same kernels would be averaged in.
+tag=${1:-round2}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# 1. kernel trace + stats of the exact bench command (no PMC in this pass)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1 || exit 1
-cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
+B="python bench.py --no-cpu-baseline --no-parity-probe"
+# 1. kernel trace of the exact bench command (no PMC in this pass)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 20 --warmup 3 > $out/bench_under_rocprof.log 2>&1 || exit 1
+grep '^{"metric"' $out/bench_under_rocprof.log > $out/${tag}_bench_under_rocprof.json
 # 2. HBM traffic counters, separate passes (FETCH_SIZE uses 3 TCC slots, WRITE_SIZE 2)
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $out/pmc_write -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $B --steps 4 --warmup 1 > $out/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $out/pmc_write -- $B --steps 4 --warmup 1 > $out/pmc_write.log 2>&1 || exit 1
 python - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections, json
 out, tag = sys.argv[1], sys.argv[2]
+
+def short(name):
+    return name.split("(")[0]
+
+# ---- kernel statistics per (kernel, grid), dominant grid only
+trace = glob.glob(out + "/trace/*/*kernel_trace.csv")[0]
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(trace)):
+    grid = (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
+    per[short(r["Kernel_Name"])][grid].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+rows = []
+for k, grids in per.items():
+    grid, d = max(grids.items(), key=lambda kv: sum(kv[1]))
+    n = len(d)
+    mean = sum(d) / n
+    sd = (sum((x - mean) ** 2 for x in d) / n) ** 0.5
+    rows.append((sum(d), k, "x".join(grid), n, mean, min(d), max(d), sd, sum(len(v) for v in grids.values()) - n))
+rows.sort(reverse=True)
+total = sum(r[0] for r in rows)
+with open("%s/%s_bench_kernel_stats.csv" % (out, tag), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Grid", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev", "CallsWithOtherGrids"])
+    for tot, k, grid, n, mean, lo, hi, sd, other in rows:
+        w.writerow([k, grid, n, tot, "%.1f" % mean, "%.2f" % (100.0 * tot / total), lo, hi, "%.1f" % sd, other])
+        print("%-60s grid %-16s calls %3d avg %9.1f us  (%d launches with other grids left out)" % (k[:60], grid, n, mean / 1e3, other))
+
+# ---- HBM traffic of the same launch shapes
+dominant = {k: g for _, k, g, *_ in rows}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
+    tr = glob.glob(f.rsplit("/", 1)[0] + "/*kernel_trace.csv")
+    grids = {}
+    if tr:
+        for r in csv.DictReader(open(tr[0])):
+            grids[r["Dispatch_Id"]] = "x".join((r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]))
     for row in csv.DictReader(open(f)):
-        agg[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        k = short(row["Kernel_Name"])
+        if "ctd::" not in k or grids.get(row["Dispatch_Id"], dominant.get(k)) != dominant.get(k):
+            continue
+        agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summ = {}
 for k, cs in agg.items():
-    if "ctd::" in k:
-        summ[k] = {c: sum(v) / len(v) for c, v in cs.items()}
-        summ[k]["launches_sampled"] = max(len(v) for v in cs.values())
+    summ[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+    summ[k]["launches_sampled"] = max(len(v) for v in cs.values())
+    summ[k]["grid"] = dominant.get(k)
+    if "FETCH_SIZE" in summ[k] and "WRITE_SIZE" in summ[k]:
+        # MI355X_MICROARCH.md: FETCH_SIZE under-reports by 2x on gfx950, WRITE_SIZE is exact; both in KiB
+        summ[k]["hbm_bytes_per_launch"] = (2.0 * summ[k]["FETCH_SIZE"] + summ[k]["WRITE_SIZE"]) * 1024.0
 json.dump(summ, open("%s/%s_pmc_hbm_traffic.json" % (out, tag), "w"), indent=1)
-print(json.dumps(summ, indent=1))
+print(json.dumps({k: v for k, v in summ.items() if "t256" in k}, indent=1))
 PY
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
