@@ -1,4 +1,6 @@
-"""Minimal training step of the disparity network on the HIP losses.
+"""Training steps of the disparity network on the HIP losses: `DisparityTrainer` (one
+scale, small network: the plumbing test) and `TrackTrainer` (BASELINE config 5 at its real shape: four scales,
+photometric + disparity + edge + geometric terms on frame tracks, the full-size network, data parallel).
 
 Own counterpart of the reference's loop -- `Worker.train_epoch` (torchext/worker.py:362-443) with the loss of
 `exp_synph.Worker.loss_forward` (model/exp_synph.py:93-118): per step
@@ -110,6 +112,116 @@ class DisparityTrainer:
                 if p.grad is not None:
                     torch.distributed.all_reduce(p.grad, group=self.pg)
                     p.grad /= torch.distributed.get_world_size(self.pg)
+        w.stop("backward")
+        w.start("optimizer")
+        self.optimizer.step()
+        w.stop("optimizer")
+        w.stop("total", sync=False)
+        return [float(v.detach()) for v in vals]
+
+
+class TrackTrainer:
+    """BASELINE config 5: one replica of the reference's multi-scale photometric + geometric training step
+    (`exp_synphge.Worker`, model/exp_synphge.py:133-202, on the loop of torchext/worker.py:362-443).
+
+    A batch is a dict of device tensors shaped like the reference's after `copy_data` (exp_synphge.py:93-115):
+        im{s}   [tl, B, 1, H_s, W_s]  raw IR frames of scale s = 0..3 (H_s = H / 2^s)
+        grad{s} [tl, B, 1, H_s, W_s]  gradient magnitude of the ground-truth disparity, scales 0..2 (edge supervision)
+        id      [B]                   sample ids; the edge decoder is supervised where id > train_edge
+        R [tl, B, 3, 3], t [tl, B, 3] camera poses of the track frames
+    Terms, in the reference's order (exp_synphge.py:141-200): photometric pattern similarity of every scale (all four
+    in one fused launch each way), `dp_weight` * edge-aware disparity loss at scale 0, BCE-with-logits edge loss of
+    scales 0..2 (pos_weight 0.1) on the supervised samples, and for every scale and every frame pair of the track the
+    two-view geometric loss on disparity -> depth, weighted `ge_weight / (tl (tl-1) / 2)`.
+
+    Data parallel: wrap happens here (`torch.nn.parallel.DistributedDataParallel`, bucketed gradient all-reduce
+    overlapped with backward, RCCL); every loss term is a per-rank mean over the rank's own samples, as DDP assumes.
+    """
+
+    def __init__(self, net, patterns, K, baseline, focal_lengths, dp_weight=0.02, ge_weight=0.1, train_edge=-1, lr=1e-4,
+                 lcn_radius=5, lcn_eps=0.05, process_group=None, device_ids=None):
+        self.device = patterns[0].device
+        self.imsizes = [(p.shape[-2], p.shape[-1]) for p in patterns]
+        self.net = net.to(self.device)
+        self.pg = process_group
+        self.model = self.net
+        if process_group is not None:
+            self.model = torch.nn.parallel.DistributedDataParallel(self.net, device_ids=device_ids,
+                                                                   process_group=process_group)
+        self.lcn = te.LCN(lcn_radius, lcn_eps)
+        self.photo = te.MultiScalePatternSimilarityLoss(patterns, loss_type="census_sad", loss_eps=0.5)
+        self.disparity_loss = te.DisparityLoss()
+        self.edge_loss = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([0.1], device=self.device))
+        self.d2d, self.geo = [], []
+        for s, (h, w) in enumerate(self.imsizes):
+            Ks = K.clone().double()
+            Ks[:2] = Ks[:2] / 2 ** s                                  # intrinsics of scale s
+            self.geo.append(te.ProjectionDepthSimilarityLoss(Ks.float(), torch.linalg.inv(Ks).float(), h, w, clamp=0.1))
+            self.d2d.append(te.DispToDepth(float(focal_lengths[s]), float(baseline)))
+        self.dp_weight, self.ge_weight, self.train_edge = dp_weight, ge_weight, train_edge
+        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=lr)
+        self.watch = StopWatch(self.device)
+
+    def copy_data(self, batch):
+        """LCN of every scale's frames (exp_synphge.py:107-115): returns per scale the network-side tensors"""
+        data = dict(batch)
+        with torch.no_grad():
+            for s in range(len(self.imsizes)):
+                im = batch["im%d" % s]
+                tl, B = im.shape[:2]
+                lcn, std = self.lcn(im.reshape(tl * B, *im.shape[2:]).contiguous())
+                data["lcn%d" % s], data["std%d" % s] = lcn, std
+        return data
+
+    def net_forward(self, data):
+        im = data["im0"]
+        x = torch.cat((data["lcn0"], im.reshape(-1, *im.shape[2:])), dim=1)     # [tl*B, 2, H, W]
+        return self.model(x)
+
+    def loss_forward(self, out, data, train=True):
+        disps, edges = out
+        tl, B = data["im0"].shape[:2]
+        n = len(self.imsizes)
+        vals = list(self.photo(disps, [data["lcn%d" % s] for s in range(n)], [data["std%d" % s] for s in range(n)])[0])
+        if self.dp_weight > 0:
+            vals.append(self.disparity_loss(disps[0], 1 - torch.sigmoid(edges[0])) * self.dp_weight)
+        sup = data["id"] > self.train_edge                                        # [B]
+        for s, e in enumerate(edges):
+            if bool(sup.any()):
+                e5 = e.view(tl, B, *e.shape[1:])[:, sup]
+                gt = (data["grad%d" % s] < 0.2).to(torch.float32)[:, sup]         # inverse edge map: 0 = edge
+                vals.append(self.edge_loss(e5.reshape(-1, *e5.shape[2:]), gt.reshape(-1, *gt.shape[2:])))
+            else:
+                vals.append(torch.zeros_like(vals[0]))
+        if not train:
+            return vals
+        ge_num = tl * (tl - 1) / 2
+        R, t = data["R"], data["t"]
+        for s in range(n):
+            depth = self.d2d[s](disps[s]).view(tl, B, *disps[s].shape[1:])
+            for i0 in range(tl):
+                for i1 in range(i0 + 1, tl):
+                    v = self.geo[s](depth[i0].contiguous(), depth[i1].contiguous(), R[i0].contiguous(), t[i0].contiguous(),
+                                    R[i1].contiguous(), t[i1].contiguous())
+                    vals.append(v * (self.ge_weight / ge_num))
+        return vals
+
+    def train_step(self, batch):
+        w = self.watch
+        w.start("total")
+        self.optimizer.zero_grad(set_to_none=True)
+        w.start("data")
+        data = self.copy_data(batch)
+        w.stop("data")
+        w.start("forward")
+        out = self.net_forward(data)
+        w.stop("forward")
+        w.start("loss")
+        vals = self.loss_forward(out, data)
+        err = sum(vals)
+        w.stop("loss")
+        w.start("backward")
+        err.backward()                                   # DDP all-reduces the gradient buckets under this
         w.stop("backward")
         w.start("optimizer")
         self.optimizer.step()

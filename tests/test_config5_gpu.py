@@ -1,0 +1,139 @@
+"""BASELINE config 5 at its real shape: the reference's multi-scale photometric + geometric training step
+(model/exp_synphge.py:133-202) -- 480x640, batch 8, track length 2, four scales, the full-size disparity / edge
+network (connecting_the_dots_amd/nets.py) -- through the HIP loss kernels, checked term by term against a path built
+from stock PyTorch ops only (grid_sample, unfold, conv2d, BCEWithLogitsLoss, bmm): same terms, same order, same
+weights.  No reference file is involved on the box; the formulas are networks.py:340-503 restated with torch ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import workloads
+
+pytestmark = pytest.mark.gpu
+
+H, W, D, B, TL = 480, 640, 128, 8, 2
+FOCAL, BASELINE = 567.6, 0.075
+
+
+def device_batch(seed, B=B, H=H, W=W):
+    nb = workloads.track_batch(seed, TL, B, H, W, D)
+    pat = nb.pop("pattern")
+    return {k: torch.from_numpy(v).cuda() for k, v in nb.items()}, pat
+
+
+def pattern_pyramid(te, pat01):
+    """LCN'd pattern of every scale (exp_synphge.py:72-77); scale s = 2x2 box average of scale s-1"""
+    pats, p = [], torch.from_numpy(pat01[None, None]).cuda()
+    for s in range(4):
+        pats.append(te.lcn(p.contiguous(), 5, 0.05)[0])
+        p = F.avg_pool2d(p, 2)
+    return pats
+
+
+def torch_photo(te, disp, im, std, pattern):
+    Bn, _, h, w = disp.shape
+    u = torch.arange(w, dtype=torch.float32, device=disp.device).view(1, 1, -1).expand(1, h, -1)
+    v = torch.arange(h, dtype=torch.float32, device=disp.device).view(1, -1, 1).expand(1, -1, w)
+    u1 = u - disp.view(Bn, h, w)
+    grid = torch.stack((2 * (u1 / (w - 1) - 0.5), (2 * (v / (h - 1) - 0.5)).expand(Bn, -1, -1)), dim=3)
+    proj = F.grid_sample(pattern.expand(Bn, -1, -1, -1), grid, padding_mode="border", align_corners=False)
+    diff = te.photometric_loss_pytorch(proj, im, 9, "census_sad", 0.5)
+    return (std * diff).sum() / std.sum()
+
+
+def torch_disparity_loss(disp, edge_logits):
+    kx = torch.tensor([[-5, -4, 0, 4, 5], [-8, -10, 0, 10, 8], [-10, -20, 0, 20, 10], [-8, -10, 0, 10, 8],
+                       [-5, -4, 0, 4, 5]], dtype=torch.float32, device=disp.device) / 240.0
+    dp = F.pad(disp, (2, 2, 2, 2), mode="replicate")
+    gx, gy = F.conv2d(dp, kx.view(1, 1, 5, 5)), F.conv2d(dp, kx.t().contiguous().view(1, 1, 5, 5))
+    g = torch.sqrt(gx * gx + gy * gy + 1e-8)
+    e = 1 - torch.sigmoid(edge_logits)
+    b0, b1 = 0.0503428816795, 1.07274045944
+    pdf = (1 - e) / b0 * torch.exp(-g / b0) + e / b1 * torch.exp(-g / b1)
+    return (-torch.log(pdf.clamp(min=1e-4))).mean()
+
+
+def torch_geometric(depth0, depth1, K, R0, t0, R1, t1, clamp):
+    Bn, _, h, w = depth0.shape
+    Ki = torch.linalg.inv(K.double()).float()
+    u = torch.arange(w, dtype=torch.float32, device=depth0.device).view(1, -1).expand(h, -1)
+    v = torch.arange(h, dtype=torch.float32, device=depth0.device).view(-1, 1).expand(-1, w)
+    ray = torch.stack((u, v, torch.ones_like(u)), dim=2).reshape(-1, 3) @ Ki.T
+    xyz = depth0.reshape(Bn, -1, 1) * ray.unsqueeze(0)
+    xyz = torch.bmm(xyz - t0.reshape(Bn, 1, 3), R0)
+    xyz = torch.bmm(xyz, R1.transpose(1, 2)) + t1.reshape(Bn, 1, 3)
+    uvd = xyz @ K.T
+    d = uvd[:, :, 2:3]
+    uv = uvd[:, :, :2] / (F.relu(d) + 1e-12)
+    grid = torch.stack((2 * (uv[:, :, 0] / (w - 1) - 0.5), 2 * (uv[:, :, 1] / (h - 1) - 0.5)), dim=2).view(Bn, h, w, 2)
+    depth10 = F.grid_sample(depth1, grid, padding_mode="border", align_corners=False)
+    return torch.clamp(torch.abs(d.view(Bn, 1, h, w) - depth10), 0, clamp).mean()
+
+
+def torch_only_terms(te, tr, out, data):
+    """every term of TrackTrainer.loss_forward from stock torch ops, same order"""
+    disps, edges = out
+    vals = []
+    for s in range(4):
+        vals.append(torch_photo(te, disps[s], data["lcn%d" % s], data["std%d" % s], tr.photo.patterns[s]))
+    vals.append(torch_disparity_loss(disps[0], edges[0]) * tr.dp_weight)
+    sup = data["id"] > tr.train_edge
+    bce = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([0.1], device="cuda"))
+    for s, e in enumerate(edges):
+        e5 = e.view(TL, -1, *e.shape[1:])[:, sup]
+        gt = (data["grad%d" % s] < 0.2).float()[:, sup]
+        vals.append(bce(e5.reshape(-1, *e5.shape[2:]), gt.reshape(-1, *gt.shape[2:])))
+    K0 = torch.tensor([[FOCAL, 0, 324.7], [0, 570.2, 250.1], [0, 0, 1]], device="cuda")
+    for s in range(4):
+        Ks = K0.clone()
+        Ks[:2] /= 2 ** s
+        depth = ((FOCAL / 2 ** s) * BASELINE / (F.relu(disps[s]) + 1e-12)).view(TL, -1, *disps[s].shape[1:])
+        R, t = data["R"], data["t"]
+        v = torch_geometric(depth[0], depth[1], Ks, R[0], t[0], R[1], t[1], 0.1) + \
+            torch_geometric(depth[1], depth[0], Ks, R[1], t[1], R[0], t[0], 0.1)
+        vals.append(v * (tr.ge_weight / 1.0))
+    return vals
+
+
+def make_trainer(te, pat01, **kw):
+    from connecting_the_dots_amd.nets import DispEdgeNet
+    from connecting_the_dots_amd.train import TrackTrainer
+    K = torch.tensor([[FOCAL, 0, 324.7], [0, 570.2, 250.1], [0, 0, 1]], device="cuda")
+    torch.manual_seed(0)
+    return TrackTrainer(DispEdgeNet(2, D), pattern_pyramid(te, pat01), K, BASELINE, [FOCAL / 2 ** s for s in range(4)], **kw)
+
+
+def test_config5_terms_match_stock_torch_at_full_size():
+    from connecting_the_dots_amd import torchext as te
+    batch, pat01 = device_batch(3)
+    tr = make_trainer(te, pat01, train_edge=B // 2 - 1)               # half of the samples carry edge supervision
+    data = tr.copy_data(batch)
+    out = tr.net_forward(data)
+    assert [tuple(d.shape[1:]) for d in out[0]] == [(1, H >> s, W >> s) for s in range(4)]
+    assert [tuple(e.shape[1:]) for e in out[1]] == [(1, H >> s, W >> s) for s in range(3)]
+    assert all(float(d.min()) >= 0 and float(d.max()) <= D / 2 ** s for s, d in enumerate(out[0]))
+    vals = tr.loss_forward(out, data)
+    ref = torch_only_terms(te, tr, out, data)
+    assert len(vals) == len(ref) == 4 + 1 + 3 + 4
+    # photometric: the fused kernel's bilinear weights differ from ATen's by rounding (1e-5 absolute in the warp);
+    # disparity / BCE / geometric: 1e-5 relative (geometric 2e-4: f32 chain of two rigid transforms at depth ~ 10)
+    tols = [2e-4] * 4 + [1e-5] + [1e-5] * 3 + [2e-4] * 4
+    for k, (a, b, tol) in enumerate(zip(vals, ref, tols)):
+        assert abs(float(a) - float(b)) <= tol * abs(float(b)) + 1e-9, (k, float(a), float(b))
+    # the summed loss drives the same gradient into the finest disparity
+    ga = torch.autograd.grad(sum(vals), out[0][0], retain_graph=True)[0]
+    gb = torch.autograd.grad(sum(ref), out[0][0])[0]
+    assert float((ga - gb).abs().mean()) <= 2e-2 * float(gb.abs().mean())
+
+
+def test_config5_training_steps_run_and_learn():
+    """a few optimiser steps on one batch at reduced size: finite, decreasing, every bucket timed"""
+    from connecting_the_dots_amd import torchext as te
+    batch, pat01 = device_batch(4, B=2, H=192, W=256)
+    tr = make_trainer(te, pat01, lr=2e-4)
+    first = sum(tr.train_step(batch))
+    for _ in range(12):
+        last = sum(tr.train_step(batch))
+    assert np.isfinite(last) and last < first, (first, last)
+    assert set(tr.watch.mean_ms()) == {"total", "data", "forward", "loss", "backward", "optimizer"}

@@ -90,3 +90,41 @@ def render_scene(seed, H=48, W=64, n_boxes=4, wall=True):
     shader = (0.5, 1.5, 0.0, 10.0)                                    # create_syn_data.py:155
     return dict(verts=verts, colors=colors, faces=faces, cam=cam, proj=proj, shader=shader, pattern=pattern,
                 d_alpha=0.0, d_beta=0.35)
+
+
+def small_pose(rs):
+    """a small seeded rigid motion (rotation by ~0.01 rad about a random axis, 2 cm translation)"""
+    ax = rs.randn(3) * 0.01
+    th = np.linalg.norm(ax)
+    k = ax / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    return R.astype(np.float32), (rs.randn(3) * 0.02).astype(np.float32)
+
+
+def track_batch(seed, tl, B, H, W, D, n_scales=4, block=(48, 64)):
+    """A synthetic training batch shaped like the reference's TrackSynDataset samples after Worker.copy_data
+    (model/exp_synphge.py:93-115): per scale s the raw IR frames im{s} [tl,B,1,H_s,W_s] (scale s = 2x2 box-averaged
+    scale s-1, the way data/dataset.py builds its pyramids), the ground-truth disparity's gradient magnitude grad{s}
+    (scales 0..2), sample ids, and per-frame poses R [tl,B,3,3], t [tl,B,3].  numpy arrays."""
+    rs = np.random.RandomState(seed)
+    pat = syn_dot_pattern(H, W, seed=42)
+    ims = np.zeros((tl, B, 1, H, W), np.float32)
+    disps = np.zeros((tl, B, 1, H, W), np.float32)
+    R = np.zeros((tl, B, 3, 3), np.float32)
+    t = np.zeros((tl, B, 3), np.float32)
+    for i in range(tl):
+        for b in range(B):
+            ims[i, b, 0], d = synth_ir(pat, rs, D, block=block)
+            disps[i, b, 0] = d
+            R[i, b], t[i, b] = small_pose(rs)
+    out = {"id": np.arange(B, dtype=np.int64), "R": R, "t": t, "pattern": pat}
+    im, dd = ims, disps
+    for s in range(n_scales):
+        out["im%d" % s] = im
+        if s < 3:
+            gy, gx = np.gradient(dd, axis=(3, 4))
+            out["grad%d" % s] = np.sqrt(gx * gx + gy * gy).astype(np.float32)
+        im = im.reshape(tl, B, 1, im.shape[3] // 2, 2, im.shape[4] // 2, 2).mean(axis=(4, 6))
+        dd = dd.reshape(tl, B, 1, dd.shape[3] // 2, 2, dd.shape[4] // 2, 2).mean(axis=(4, 6)) / 2
+    return out
