@@ -7,7 +7,12 @@ this package: CPU tensors raise (the reference's CPU path is `ext_cpu`, which li
 the test oracle only).
 
 Additive API (no reference counterpart): `xcorrvol_batch`, `argmax_disp`,
-`xcorrvol_argmax`, `lcn`.
+`xcorrvol_argmax`, `lcn`, ... and the keyword `algo` of the ops that have two kernel families:
+    'fast'  (default) tolerance-level kernels, |a-b| <= 1e-5*|b| + 1e-6 against the reference (LDS-tiled, HBM- or
+            issue-bound; f32 and odd block sizes up to 9 -- anything else runs the reference-order kernels);
+    'exact' the reference's operation order, bit-identical to its CPU build (the parity anchor).
+The default can be changed with the environment variables CTD_NCC_ALGO (xcorrvol family) and CTD_PHOTO_ALGO
+(photometric loss, cost volumes, pattern similarity loss).
 """
 import os
 
@@ -19,7 +24,12 @@ _ALGOS = {"exact": 0, "fast": 1}
 
 
 def _default_algo():
-    return os.environ.get("CTD_NCC_ALGO", "exact")
+    return os.environ.get("CTD_NCC_ALGO", "fast")
+
+
+def _ncc_fast_covers(dtype, n_disps, block_size):
+    """the separable-sum kernels: f32, block 3/5/7/9, D <= 512; everything else is the reference-order kernel's"""
+    return dtype == torch.float32 and int(block_size) in (3, 5, 7, 9) and int(n_disps) <= 512
 
 
 def _check(t, name, dtypes=(torch.float32, torch.float64)):
@@ -160,6 +170,10 @@ def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):
         raise RuntimeError("in1 batch does not match in0")
     D, bs = int(n_disps), int(block_size)
     out = torch.empty((N, D, H, W), dtype=in0.dtype, device=dev)
+    if algo not in _ALGOS:
+        raise RuntimeError("unknown algo %r" % (algo,))
+    if algo == "fast" and not _ncc_fast_covers(in0.dtype, D, bs):
+        algo = "exact"
     a = _ALGOS[algo]
     ws_bytes = L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a)
     ws = _workspace(ws_bytes, dev)
@@ -175,21 +189,22 @@ def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):
 
 class XCorrVolFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, in0, in1, n_disps, block_size):
+    def forward(ctx, in0, in1, n_disps, block_size, algo=None):
         _check(in0, "in0")
         _check(in1, "in1")
         if in0.dim() != 3 or in1.dim() != 3:
             raise RuntimeError("xcorrvol expects [C,H,W] tensors")
-        return _xcorrvol_impl(in0.unsqueeze(0), in1, n_disps, block_size, _default_algo())[0]
+        return _xcorrvol_impl(in0.unsqueeze(0), in1, n_disps, block_size, algo or _default_algo())[0]
 
     @staticmethod
     def backward(ctx, grad_out):
-        return None, None, None, None
+        return None, None, None, None, None
 
 
-def xcorrvol(in0, in1, n_disps, block_size):
-    """Zero-mean NCC volume [D,H,W] between in0 [C,H,W] at (h,w) and in1 at (h,w-d)."""
-    return XCorrVolFunction.apply(in0, in1, n_disps, block_size)
+def xcorrvol(in0, in1, n_disps, block_size, algo=None):
+    """Zero-mean NCC volume [D,H,W] between in0 [C,H,W] at (h,w) and in1 at (h,w-d).
+    algo (additive): 'fast' (default) | 'exact', see the module docstring."""
+    return XCorrVolFunction.apply(in0, in1, n_disps, block_size, algo)
 
 
 def xcorrvol_batch(in0, in1, n_disps, block_size, algo=None):
@@ -235,7 +250,12 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
         raise RuntimeError("in0 and in1 must have the same [C,H,W] shape")
     stride1 = 0 if in1.dim() == 3 else C * H * W
     D, bs = int(n_disps), int(block_size)
-    a = _ALGOS[algo or _default_algo()]
+    algo = algo or _default_algo()
+    if algo not in _ALGOS:
+        raise RuntimeError("unknown algo %r" % (algo,))
+    if algo == "fast" and not _ncc_fast_covers(a0.dtype, D, bs):
+        algo = "exact"
+    a = _ALGOS[algo]
     idx = torch.empty((N, H, W), dtype=torch.int64, device=dev)
     best = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     # the fast path ranks inside the volume kernel where it can (no volume needed); other shapes rank a materialised one
@@ -303,9 +323,9 @@ def _photo_args(es, ta):
 
 
 def _photo_fast(es, block_size, algo):
-    """algo 'fast' = tolerance-level kernels (f32, odd block sizes up to 9); anything else they do not cover
-    runs the reference-order kernels."""
-    algo = algo or os.environ.get("CTD_PHOTO_ALGO", "exact")
+    """algo 'fast' (default) = tolerance-level kernels (f32, odd block sizes up to 9); anything else they do not
+    cover runs the reference-order kernels."""
+    algo = algo or os.environ.get("CTD_PHOTO_ALGO", "fast")
     if algo not in _ALGOS:
         raise RuntimeError("unknown algo %r" % (algo,))
     return algo == "fast" and es.dtype == torch.float32 and int(block_size) in (3, 5, 7, 9)
@@ -356,8 +376,8 @@ _PHOTO_TYPES = {"mse": 0, "sad": 1, "census_mse": 2, "census_sad": 3}
 def photometric_loss(es, ta, block_size, type='mse', eps=0.1, algo=None):
     """[B,C,H,W] x2 -> [B,1,H,W]: mean over a block_size^2 replicate-clamped block, summed over channels, of
     (es-ta)^2 | |es-ta| | soft-census squared / absolute difference.  Gradient flows to `es` only.
-    algo (additive): 'exact' = reference operation order, bit-identical to the reference CPU build (default, or
-    env CTD_PHOTO_ALGO); 'fast' = tolerance-level kernels, ~10x faster for the census types."""
+    algo (additive): 'fast' (default, or env CTD_PHOTO_ALGO) = tolerance-level kernels, ~10x faster for the census
+    types; 'exact' = reference operation order, bit-identical to the reference CPU build."""
     type = type.lower()
     if type not in _PHOTO_TYPES:
         raise Exception('invalid loss type')                  # functions.py:117

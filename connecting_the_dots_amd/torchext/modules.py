@@ -52,7 +52,7 @@ class RectifiedPatternSimilarityLoss(torch.nn.Module):
 
     def __init__(self, im_height, im_width, pattern, loss_type='census_sad', loss_eps=0.5, algo=None):
         super().__init__()
-        self.algo = algo                      # additive: 'exact' (default) | 'fast', see photometric_loss
+        self.algo = algo                      # additive: 'fast' (default) | 'exact', see photometric_loss
         self.im_height = im_height
         self.im_width = im_width
         self.pattern = pattern.mean(dim=1, keepdim=True).contiguous()
@@ -88,7 +88,7 @@ class RectifiedPatternSimilarityLoss(torch.nn.Module):
 
     def _fused(self, disp0, im, std):
         import os
-        algo = self.algo or os.environ.get("CTD_PHOTO_ALGO", "exact")
+        algo = self.algo or os.environ.get("CTD_PHOTO_ALGO", "fast")
         return (algo == "fast" and disp0.dtype == torch.float32 and disp0.dim() == 4 and disp0.shape[1] == 1
                 and im.shape == disp0.shape and (std is None or std.shape == disp0.shape)
                 and not im.requires_grad and (std is None or not std.requires_grad))

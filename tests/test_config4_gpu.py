@@ -87,7 +87,7 @@ def test_census_cost_volume_strips_and_shift_recovery(te, oracle, data):
     true_d = 37
     cols = (torch.arange(W, device="cuda") - true_d).clamp(0, W - 1)
     shifted = p[0][:, cols].contiguous()
-    cost = te.costvol(shifted, p[0], D, BS, "census_sad", 0.5)
+    cost = te.costvol(shifted, p[0], D, BS, "census_sad", 0.5, algo="exact")
     assert cost.shape == (D, H, W)
     arg = cost.argmin(0)
     inner = arg[8:-8, true_d + 8:-8]
@@ -100,3 +100,26 @@ def test_census_cost_volume_strips_and_shift_recovery(te, oracle, data):
         lo, hi = strip_rows(r0)
         got = cost[:48, r0 + lo:r0 + hi].cpu().numpy()
         assert np.array_equal(got, ref[:, lo:hi]), "strip at row %d" % r0
+
+
+@pytest.mark.parametrize("kind", ["census_sad", "sad"])
+def test_lds_tiled_cost_volume_at_full_size(te, oracle, data, kind):
+    """the LDS-tiled cost-volume kernel (algo='fast', the package default) at the config-4 size -- 8 disparity chunks
+    of 32 per tile, frames * D = 256 grid planes: every one of the 268 M outputs within the float tolerance of the
+    reference-order kernel (itself bit-identical to the oracle, test above), plus strips against the oracle directly"""
+    x, p = data
+    true_d = 37
+    cols = (torch.arange(W, device="cuda") - true_d).clamp(0, W - 1)
+    shifted = p[0][:, cols].contiguous()
+    fast = te.costvol(shifted, p[0], D, BS, kind, 0.5, algo="fast")
+    exact = te.costvol(shifted, p[0], D, BS, kind, 0.5, algo="exact")
+    bad = (fast - exact).abs() > exact.abs() * 1e-5 + 1e-6
+    assert int(bad.sum()) == 0, "%d outputs outside tolerance, max |a-b| %.3e" % (int(bad.sum()), float((fast - exact).abs().max()))
+    del exact, bad
+    assert torch.equal(fast.argmin(0)[8:-8, true_d + 8:-8], torch.full((H - 16, W - true_d - 16), true_d, device="cuda"))
+    sn, pn = shifted.cpu().numpy(), p[0].cpu().numpy()
+    ty = {"sad": 1, "census_sad": 3}[kind]
+    for r0 in STRIPS:
+        ref = oracle.costvol(sn[r0:r0 + 12], pn[r0:r0 + 12], 48, BS, ty, 0.5, nthreads=8)
+        lo, hi = strip_rows(r0)
+        assert_close(fast[:48, r0 + lo:r0 + hi].cpu().numpy(), ref[:, lo:hi], what="%s strip at row %d" % (kind, r0))

@@ -112,7 +112,7 @@ def test_config5_terms_match_stock_torch_at_full_size():
     out = tr.net_forward(data)
     assert [tuple(d.shape[1:]) for d in out[0]] == [(1, H >> s, W >> s) for s in range(4)]
     assert [tuple(e.shape[1:]) for e in out[1]] == [(1, H >> s, W >> s) for s in range(3)]
-    assert all(float(d.min()) >= 0 and float(d.max()) <= D / 2 ** s for s, d in enumerate(out[0]))
+    assert all(float(d.detach().min()) >= 0 and float(d.detach().max()) <= D / 2 ** s for s, d in enumerate(out[0]))
     vals = tr.loss_forward(out, data)
     ref = torch_only_terms(te, tr, out, data)
     assert len(vals) == len(ref) == 4 + 1 + 3 + 4

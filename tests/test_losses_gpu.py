@@ -87,3 +87,13 @@ def test_geometric_loss(te, tag, clamp):
     # in the rounding of ix - floor(ix)
     assert_close(d0.grad.cpu().numpy(), g["ge_%s_g0" % tag], rtol=2e-3, atol=2e-7, what="grad depth0")
     assert_close(d1.grad.cpu().numpy(), g["ge_%s_g1" % tag], rtol=2e-3, atol=2e-7, what="grad depth1")
+
+
+def test_idx_to_depth_matches_disp_to_depth(te):
+    """additive op: depth straight from the int64 argmax indices (+ offset) == DispToDepth on the float disparity"""
+    idx = torch.randint(0, 128, (3, 40, 64), device="cuda", dtype=torch.int64)
+    got = te.idx_to_depth(idx, 567.6 * 0.075, 1.0)
+    ref = te.DispToDepth(567.6, 0.075)(idx.to(torch.float32) + 1.0)
+    assert got.dtype == torch.float32 and torch.equal(got, ref)
+    with pytest.raises(RuntimeError):
+        te.idx_to_depth(idx.to(torch.int32), 1.0)

@@ -12,6 +12,13 @@ from tests.util import golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def reference_order_kernels(monkeypatch):
+    """this module pins the reference-order kernels (bit-exact asserts): the package default is algo='fast'"""
+    monkeypatch.setenv("CTD_NCC_ALGO", "exact")
+    monkeypatch.setenv("CTD_PHOTO_ALGO", "exact")
+
+
 @pytest.fixture(scope="module")
 def te():
     assert torch.cuda.is_available(), "GPU tests need a MI355X"
