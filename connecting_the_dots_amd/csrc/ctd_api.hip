@@ -101,14 +101,13 @@ int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, 
 int ctd_xcorrvol_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C,
                      int H, int W, int D, int block_size, void* workspace, size_t workspace_bytes, int device,
                      void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
   if (frames == 0) return CTD_OK;
   if (!in0 || !in1 || !out) return CTD_ERR_INVALID_ARG;
   DeviceGuard g(device);
   if (g.status) return g.status;
-  return ncc_exact_f64(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, (hipStream_t)stream);
+  return ncc_exact_f64(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
+                       (hipStream_t)stream);
 }
 
 int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int D, int H, int W, int device,

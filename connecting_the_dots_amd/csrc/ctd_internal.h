@@ -14,7 +14,7 @@ size_t ncc_exact_workspace_bytes(int frames, int C, int H, int W, int D, int bs,
 int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
                   int W, int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int ncc_exact_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C, int H,
-                  int W, int D, int bs, hipStream_t stream);
+                  int W, int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
                          float* best, int frames, int H, int W, int D, int bs, void* workspace,
                          size_t workspace_bytes, hipStream_t stream);

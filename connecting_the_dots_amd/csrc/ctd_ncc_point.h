@@ -1,7 +1,7 @@
-// ctd_ncc_point.h -- one NCC output in the reference's operation order, straight from global memory.
+// ctd_ncc_point.h -- one NCC output in the reference's operation order from windows staged in LDS.
 // XCorrVolFunctor<T>::operator()  /root/reference/torchext/ext/ext.h:120-191 (two passes over the window,
-// means first, channels accumulated in order).  Used by the generic fallback kernel and by the fix-up pass
-// of the fast path; bit-identical to the reference's FMA-free CPU build.
+// means first, channels accumulated in order).  Used by the exact re-scoring of the ranked argmax
+// (argmax_rerank.hip); bit-identical to the reference's FMA-free CPU build.
 #ifndef CTD_NCC_POINT_H
 #define CTD_NCC_POINT_H
 #include "ctd_common.h"
@@ -13,45 +13,6 @@ __device__ inline float ncc_norm(float s0, float s1) {
   return (float)((double)sqrtf(s0 * s1) + 1e-8);
 }
 __device__ inline double ncc_norm(double s0, double s1) { return sqrt(s0 * s1) + 1e-8; }
-
-// a, b: [C][H][W] planes of one frame / its pattern
-template <typename T>
-__device__ inline T ncc_reference_point(const T* __restrict__ a, const T* __restrict__ b, int C, int H, int W, int h,
-                                        int w, int d, int bs) {
-  const long HW = (long)H * W;
-  const int half = bs / 2;
-  const T bs2 = (T)(bs * bs);
-  T val = 0;
-  for (int c = 0; c < C; ++c) {
-    T mu0 = 0, mu1 = 0;
-    for (int bh = 0; bh < bs; ++bh) {
-      int hh = clampi(h + bh - half, 0, H - 1);
-      for (int bw = 0; bw < bs; ++bw) {
-        int w0 = w + bw - half;
-        int w1 = clampi(w0 - d, 0, W - 1);
-        w0 = clampi(w0, 0, W - 1);
-        mu0 += a[(long)c * HW + (long)hh * W + w0] / bs2;
-        mu1 += b[(long)c * HW + (long)hh * W + w1] / bs2;
-      }
-    }
-    T s0 = 0, s1 = 0, dot = 0;
-    for (int bh = 0; bh < bs; ++bh) {
-      int hh = clampi(h + bh - half, 0, H - 1);
-      for (int bw = 0; bw < bs; ++bw) {
-        int w0 = w + bw - half;
-        int w1 = clampi(w0 - d, 0, W - 1);
-        w0 = clampi(w0, 0, W - 1);
-        T v0 = a[(long)c * HW + (long)hh * W + w0] - mu0;
-        T v1 = b[(long)c * HW + (long)hh * W + w1] - mu1;
-        dot += v0 * v1;
-        s0 += v0 * v0;
-        s1 += v1 * v1;
-      }
-    }
-    val += dot / ncc_norm(s0, s1);
-  }
-  return val;
-}
 
 // reference-order NCC of one disparity from windows staged in LDS: sA[bs][bs] is the frame window,
 // sB[bs][bs + D - 1] the pattern rows from column w - half - (D-1) on (replicate border baked in), so tap

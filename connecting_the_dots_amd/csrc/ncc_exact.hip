@@ -190,20 +190,108 @@ __global__ __launch_bounds__(kTW* kTH, 3) void ncc_exact_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// generic fallback: any block size, f32 or f64, one thread per output exactly like the
-// reference functor (two passes over the window straight from global memory).
+// generic LDS-tiled kernel: any block size (even ones too: the window is rows h - bs/2 .. h - bs/2 + bs - 1,
+// ext.h:148-150), f32 or f64 -- what the reference's AT_DISPATCH_FLOATING_TYPES covers (ext_kernel.cu:45) beyond the
+// compile-time f32 kernel above.  Same decomposition: window means / sums of squared deviations hoisted into
+// window_stats_kernel (reference tap order, so the bits are the reference's), a 64 x 4 pixel tile, the frame tile and
+// the pattern rows for ALL disparities staged in LDS with the replicate border baked in; a thread then walks the
+// disparities of its pixel with the taps coming from LDS (2 bs^2 LDS reads per output where the reference's kernel
+// makes 4 bs^2 global loads).  dot accumulates in the reference's order, multiply and add unfused.
+//   grid (ceil(W/64), ceil(H/4), frames), block (64, 4); LDS (4 + bs - 1) x ((64 + bs - 1) + (64 + bs - 1 + D - 1)) T
 // ---------------------------------------------------------------------------------
 template <typename T>
-__global__ void ncc_direct_kernel(const T* __restrict__ in0, const T* __restrict__ in1, long in1_frame_stride,
-                                  T* __restrict__ out, int C, int H, int W, int D, int bs, long total) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+struct Stat2 { T mu, sigma; };
+
+template <typename T>
+__global__ __launch_bounds__(kTW* kTH) void ncc_tiled_generic_kernel(
+    const T* __restrict__ in0, const T* __restrict__ in1, long in1_frame_stride, const Stat2<T>* __restrict__ stats0,
+    const Stat2<T>* __restrict__ stats1, T* __restrict__ out, int C, int H, int W, int D, int bs) {
+  extern __shared__ double smem_generic[];
+  T* tile0 = (T*)smem_generic;
+  const int half = bs / 2;
+  const int TR = kTH + bs - 1, TW0 = kTW + bs - 1, TW1 = kTW + bs - 1 + D - 1;
+  T* tile1 = tile0 + TR * TW0;
+  const int W1 = W + D - 1;                    // stats1 row: x = w - d in [-(D-1), W-1]
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTW + tx;
+  const int w_lo = blockIdx.x * kTW, h_lo = blockIdx.y * kTH, f = blockIdx.z;
+  const int w = w_lo + tx, h = h_lo + ty;
+  const bool active = (w < W) && (h < H);
   const long HW = (long)H * W;
-  int w = (int)(i % W);
-  int h = (int)((i / W) % H);
-  int d = (int)((i / HW) % D);
-  int f = (int)(i / (HW * D));
-  out[i] = ncc_reference_point(in0 + (long)f * C * HW, in1 + (long)f * in1_frame_stride, C, H, W, h, w, d, bs);
+  const T* img0 = in0 + (long)f * C * HW;
+  const T* img1 = in1 + (long)f * in1_frame_stride;
+  const Stat2<T>* st0 = stats0 + (long)f * C * HW;
+  const Stat2<T>* st1 = stats1 + (in1_frame_stride ? (long)f * C * H * W1 : 0);
+  T* vol = out + (long)f * D * HW;
+  const int x0_tile1 = w_lo - half - (D - 1);
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int i = tid; i < TR * TW0; i += kTW * kTH) {
+      const int r = i / TW0, col = i - r * TW0;
+      tile0[i] = img0[(long)c * HW + (long)clampi(h_lo + r - half, 0, H - 1) * W + clampi(w_lo + col - half, 0, W - 1)];
+    }
+    for (int i = tid; i < TR * TW1; i += kTW * kTH) {
+      const int r = i / TW1, col = i - r * TW1;
+      tile1[i] = img1[(long)c * HW + (long)clampi(h_lo + r - half, 0, H - 1) * W + clampi(x0_tile1 + col, 0, W - 1)];
+    }
+    __syncthreads();
+    if (!active) continue;
+    const Stat2<T> s0 = st0[(long)c * HW + (long)h * W + w];
+    const Stat2<T>* st1x = st1 + ((long)c * H + h) * W1 + (D - 1) + w;       // st1x[-d] <-> x = w - d
+    for (int d = 0; d < D; ++d) {
+      const Stat2<T> s1 = st1x[-d];
+      const T* r0 = tile0 + ty * TW0 + tx;
+      const T* r1 = tile1 + ty * TW1 + tx + (D - 1) - d;
+      T dot = 0;
+      for (int bh = 0; bh < bs; ++bh)
+        for (int bw = 0; bw < bs; ++bw) {
+          const T v0 = r0[bh * TW0 + bw] - s0.mu;
+          const T v1 = r1[bh * TW1 + bw] - s1.mu;
+          const T p = v0 * v1;                    // separate multiply and add (-ffp-contract=off): ext.h:179, no FMA
+          dot = dot + p;
+        }
+      const long o = (long)d * HW + (long)h * W + w;
+      T val = c == 0 ? (T)0 : vol[o];             // channels accumulate in order (ext.h:142,186)
+      val += dot / ncc_norm(s0.sigma, s1.sigma);
+      vol[o] = val;
+    }
+  }
+}
+
+template <typename T>
+size_t generic_workspace_bytes(int frames, int C, int H, int W, int D, bool per_frame_pattern) {
+  const size_t n0 = align_up((size_t)frames * C * H * W * sizeof(Stat2<T>), 256);
+  const size_t n1 = align_up((size_t)(per_frame_pattern ? frames : 1) * C * H * (W + D - 1) * sizeof(Stat2<T>), 256);
+  return n0 + n1;
+}
+
+template <typename T>
+static int launch_generic(const T* in0, const T* in1, long in1_frame_stride, T* out, int frames, int C, int H, int W, int D,
+                          int bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const bool per_frame = in1_frame_stride != 0;
+  if (workspace == nullptr || workspace_bytes < generic_workspace_bytes<T>(frames, C, H, W, D, per_frame))
+    return CTD_ERR_WORKSPACE;
+  const size_t lds = sizeof(T) * (size_t)(kTH + bs - 1) * ((kTW + bs - 1) + (kTW + bs - 1 + D - 1));
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  Stat2<T>* stats0 = (Stat2<T>*)workspace;
+  Stat2<T>* stats1 = (Stat2<T>*)((char*)workspace + align_up((size_t)frames * C * H * W * sizeof(Stat2<T>), 256));
+  const int W1 = W + D - 1;
+  long total = (long)frames * C * H * W;
+  hipLaunchKernelGGL(window_stats_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0,
+                     (long)C * H * W, (T*)stats0, C, H, W, 0, W, bs, total);
+  CTD_LAUNCH_CHECK();
+  total = (long)(per_frame ? frames : 1) * C * H * W1;
+  hipLaunchKernelGGL(window_stats_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in1,
+                     in1_frame_stride, (T*)stats1, C, H, W, -(D - 1), W1, bs, total);
+  CTD_LAUNCH_CHECK();
+  auto kern = ncc_tiled_generic_kernel<T>;
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), frames), block(kTW, kTH);
+  timing_begin(stream);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, in0, in1, in1_frame_stride, stats0, stats1, out, C, H, W, D, bs);
+  timing_end(stream, W);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
 }
 
 // argmax over d of a materialised volume; first index wins (strict >), one thread per pixel.
@@ -306,8 +394,11 @@ static bool exact_has_tiled(int bs) { return bs == 3 || bs == 5 || bs == 7 || bs
 
 // entry points used by ctd_api.hip -------------------------------------------------
 size_t ncc_exact_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern) {
-  if (!exact_has_tiled(bs)) return 256;
-  return exact_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
+  // worst case over the f32 kernels and the generic f64 one (the caller sizes one workspace per call)
+  const size_t g = generic_workspace_bytes<double>(frames, C, H, W, D, per_frame_pattern);
+  if (!exact_has_tiled(bs)) return g;
+  const size_t t = exact_workspace(nullptr, frames, C, H, W, D, per_frame_pattern).bytes;
+  return t > g ? t : g;
 }
 
 int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
@@ -318,20 +409,12 @@ int ncc_exact_f32(const float* in0, const float* in1, long in1_frame_stride, flo
     return dispatch_exact<true, false>(bs, in0, in1, in1_frame_stride, out, nullptr, nullptr, frames, C, H, W, D,
                                        workspace, stream);
   }
-  long total = (long)frames * D * H * W;
-  hipLaunchKernelGGL(ncc_direct_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0, in1,
-                     in1_frame_stride, out, C, H, W, D, bs, total);
-  CTD_LAUNCH_CHECK();
-  return CTD_OK;
+  return launch_generic<float>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, bs, workspace, workspace_bytes, stream);
 }
 
 int ncc_exact_f64(const double* in0, const double* in1, long in1_frame_stride, double* out, int frames, int C, int H,
-                  int W, int D, int bs, hipStream_t stream) {
-  long total = (long)frames * D * H * W;
-  hipLaunchKernelGGL(ncc_direct_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in0, in1,
-                     in1_frame_stride, out, C, H, W, D, bs, total);
-  CTD_LAUNCH_CHECK();
-  return CTD_OK;
+                  int W, int D, int bs, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return launch_generic<double>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, bs, workspace, workspace_bytes, stream);
 }
 
 int ncc_exact_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
