@@ -198,6 +198,43 @@ def parity_probe(te, device):
         return None
 
 
+def also_measured(te, L, frames, pat_lcn, args):
+    """SURVEY 8d asks for two more numbers next to the step: (i) the volume-materialising kernel alone (no ranking in
+    its epilogue: what ctd_xcorrvol_f32 launches), priced against the same roofline, and (ii) the fused, volume-free
+    LCN -> NCC -> argmax (nothing materialised; bytes are inputs + indices only, so no HBM roofline applies).  Timed
+    after the headline region, 10 repetitions each, same inputs."""
+    import ctypes
+    import torch
+    x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+    for _ in range(2):
+        te.xcorrvol_batch(x, pat_lcn, D, BS, algo="fast")
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_enable(1)
+    for _ in range(10):
+        te.xcorrvol_batch(x, pat_lcn, D, BS, algo="fast")
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_enable(0)
+    ms, cols = ctypes.c_double(0), ctypes.c_int(0)
+    n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
+    units = args.frames * H * cols.value * D
+    plain = {"kernel": "ncc_fast_t256_kernel (volume only)", "avg_launch_ms": ms.value, "launches": n,
+             "achieved_GBs": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 if n else None,
+             "frac_of_hbm_peak": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
+    for _ in range(3):
+        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        te.xcorrvol_argmax(xx, pat_lcn, D, BS)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        idx, _ = te.xcorrvol_argmax(xx, pat_lcn, D, BS)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    fused = {"what": "LCN -> NCC -> argmax with reference indices, no volume materialised", "ms_per_step": dt * 1e3,
+             "value": args.frames * H * W * D / dt / 1e6, "unit": "Mpix*disp/s"}
+    return {"volume_kernel_alone": plain, "fused_volume_free": fused}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -345,6 +382,8 @@ def main():
         }
         if geo is not None and losses:
             out["config"]["loss_allgather"] = [float(v) for v in losses[-1].flatten().tolist()]
+        if world == 1 and args.algo == "fast":
+            out["also_measured"] = also_measured(te, L, frames, pat_lcn, args)
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[:min(args.frames, 32)].cpu())
         print(json.dumps(out), flush=True)
