@@ -1100,6 +1100,21 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       for (int k = 0; k < kTRankFloats / 256; ++k) *(f32x4*)(rank_lds + 256 * k + 4 * lane) = ninf;
     }
   }
+  // slot pair (top t, second q) of the lane's four columns -> the partial word of output row hh.  The tie flag uses
+  // the margin of |top| <= 2 (scores are correlations), a constant: strict >, so that a group the run mask emptied
+  // (top = second = -inf) gets no flag -- the word would turn into a NaN.
+  const float flag_margin = rank_eps >= 0.f ? rank_margin(rank_eps, 2.f) : -INFINITY;
+  auto rank_emit = [&](f32x4 t, f32x4 q, int hh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int close = q[i] > t[i] - flag_margin ? 16 : 0;
+      t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
+    }
+    // opaque uniform offset + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane pointer to keep
+    long roff = (long)hh * W + w_lo;                                // (an opaque POINTER would turn the store into a flat one)
+    asm("" : "+s"(roff));
+    if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + roff + l4));
+  };
   // rows of chunk `ch` whose read-out falls to this wavefront: slots -> partial plane, reset
   auto rank_readout = [&](int ch) {
     float* sb = rank_lds + (ch % kTRankBufs) * (kTRows * 2 * 256) + lane;
@@ -1113,16 +1128,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         for (int i = 0; i < 4; ++i) { t[i] = sl[64 * i]; q[i] = sl[256 + 64 * i]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sl[64 * i] = -INFINITY; sl[256 + 64 * i] = -INFINITY; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // (a group the run mask emptied keeps top = -inf: no flag, or the word would turn into a NaN)
-          const int close = (rank_eps >= 0.f && t[i] > -INFINITY && q[i] >= t[i] - rank_margin(rank_eps, t[i])) ? 16 : 0;
-          t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
-        }
-        // opaque uniform base + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane pointer to keep
-        long roff = (long)hh * W + w_lo;                            // (an opaque POINTER would turn the store into a flat one)
-        asm("" : "+s"(roff));
-        if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + roff + l4));
+        rank_emit(t, q, hh);
       }
     }
   };
@@ -1154,8 +1160,23 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
     for (int u = 0; u < STEP; ++u) {
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
+      // Read-out of the chunk before last, one of its rows per row of this chunk, by the wavefront whose turn it is:
+      // the slot reads are requested here, ahead of the row's operands, and turned into the partial word only after
+      // phase A -- the read-out wave is the straggler of its chunk barrier, so its LDS round trip must not be exposed.
+      bool ro = false;
+      int ro_h = 0;
+      float* ro_sl = rank_lds;
+      f32x4 ro_t, ro_q;
+      asm("" : "=v"(ro_t), "=v"(ro_q));                            // defined (no code) on the path that reads nothing
       if constexpr (RANK) {
-        if ((u % kTRows) == 0 && chunk > 1) rank_readout(chunk - 2);
+        const int rch = chunk - 2, rs = u % kTRows;
+        ro_h = r_begin + rch * kTRows + rs - TAIL;
+        ro = rch >= 0 && ro_h >= h_lo && ro_h < h_hi && (rs + rch) % n_active == WAVE;      // wave-uniform
+        if (ro) {
+          ro_sl = rank_lds + ((rch % kTRankBufs) * kTRows + rs) * (2 * 256) + lane;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ro_t[i] = ro_sl[64 * i]; ro_q[i] = ro_sl[256 + 64 * i]; }
+        }
       }
       // Phase A, every row: products and the vertical 3+3+3 rings of both disparities (needs only the two value
       // quads).  Phase B, output rows only (wave-uniform branch; the (bs-1) warm-up rows of a band skip it):
@@ -1207,7 +1228,14 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           T[j][i][u % 6] = t3;
         }
       // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
-      if constexpr (RANK) rank_second();
+      if constexpr (RANK) {
+        rank_second();
+        if (ro) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ro_sl[64 * i] = -INFINITY; ro_sl[256 + 64 * i] = -INFINITY; }
+          rank_emit(ro_t, ro_q, ro_h);
+        }
+      }
       auto prefetch_next = [&]() {                                 // next row of the same chunk: one ring row further
         if (!last_of_chunk) {
           qa = quad(own + kTPack);
