@@ -8,6 +8,7 @@
 using namespace ctd;
 
 namespace ctd {
+// Bench instrumentation (ctd_kernel_timing_*): process-global, one bench thread (documented in the header).
 static bool g_timing = false;
 static int g_timing_columns = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
@@ -15,13 +16,21 @@ static hipEvent_t g_pending = nullptr;
 bool timing_enabled() { return g_timing; }
 void timing_begin(hipStream_t stream) {
   if (!g_timing) return;
+  if (g_pending) {                                   // a launch failed between begin and end: do not leak its event
+    (void)hipEventDestroy(g_pending);
+    g_pending = nullptr;
+  }
   if (hipEventCreate(&g_pending) != hipSuccess) { g_pending = nullptr; return; }
   (void)hipEventRecord(g_pending, stream);
 }
 void timing_end(hipStream_t stream, int columns) {
   if (!g_timing || !g_pending) return;
   hipEvent_t stop;
-  if (hipEventCreate(&stop) != hipSuccess) return;
+  if (hipEventCreate(&stop) != hipSuccess) {
+    (void)hipEventDestroy(g_pending);
+    g_pending = nullptr;
+    return;
+  }
   (void)hipEventRecord(stop, stream);
   g_events.emplace_back(g_pending, stop);
   g_pending = nullptr;
@@ -33,7 +42,13 @@ extern "C" {
 
 int ctd_version(void) { return 1; }
 
-void ctd_kernel_timing_enable(int enable) { g_timing = enable != 0; }
+void ctd_kernel_timing_enable(int enable) {
+  g_timing = enable != 0;
+  if (!g_timing && g_pending) {
+    (void)hipEventDestroy(g_pending);
+    g_pending = nullptr;
+  }
+}
 
 int ctd_kernel_timing_collect(double* avg_ms, int* columns) {
   double total = 0;

@@ -56,6 +56,9 @@ def test_exact_volume_strips_bit_exact(te, oracle, data):
 
 
 def test_fast_volume_tolerance_and_argmax_bit_parity(te, data):
+    """fast (ranked) path against the reference-order HIP kernel at full size -- the checker is HIP too, but it is
+    the kernel the previous test pins to the oracle bit for bit on strips of this very input (and to the reference's
+    goldens in test_xcorrvol_gpu.py).  Also the volume-free ranked argmax at this size."""
     x, p = data
     exact = te.xcorrvol_batch(x[None], p, D, BS, algo="exact")[0]
     idx_f, best_f, fast = te.xcorrvol_argmax(x[None], p, D, BS, return_volume=True, algo="fast")
@@ -70,6 +73,9 @@ def test_fast_volume_tolerance_and_argmax_bit_parity(te, data):
     assert torch.equal(idx_e[0], exact.argmax(0))
     assert torch.equal(best_e[0], exact.max(0).values)
     assert idx_f.dtype == torch.int64 and int(idx_f.max()) < D and int(idx_f.min()) >= 0
+    del fast, exact
+    idx_n, _ = te.xcorrvol_argmax(x[None], p, D, BS, algo="fast")             # nothing materialised
+    assert torch.equal(idx_n, idx_e)
 
 
 def test_self_match_is_one_at_zero_disparity(te, data):
