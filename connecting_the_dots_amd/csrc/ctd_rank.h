@@ -22,6 +22,30 @@ __device__ inline void worklist_push(bool take, int64_t item, unsigned* __restri
   if (take) list[base + __popcll(m & ((1ull << lane) - 1ull))] = item;
 }
 
+// Same for N candidate items per lane with ONE counter update per wavefront (a lone wavefront per fix-up item pays a
+// full global round trip for every atomic it waits on).
+template <int N>
+__device__ inline void worklist_push_n(const bool (&take)[N], const long (&item)[N], unsigned* __restrict__ counter,
+                                       int64_t* __restrict__ list) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long m[N];
+  unsigned total = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    m[i] = __ballot(take[i]);
+    total += (unsigned)__popcll(m[i]);
+  }
+  if (total == 0) return;                                      // wave-uniform
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(counter, total);
+  base = __shfl(base, 0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (take[i]) list[base + __popcll(m[i] & ((1ull << lane) - 1ull))] = item[i];
+    base += (unsigned)__popcll(m[i]);
+  }
+}
+
 // Claims pixel `pix` for the work list: true for exactly one caller per pixel (flag byte set atomically).
 __device__ inline bool worklist_claim(unsigned* __restrict__ flags, long pix) {
   const unsigned bit = 1u << (8 * (unsigned)(pix & 3));

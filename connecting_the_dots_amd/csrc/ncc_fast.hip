@@ -224,8 +224,173 @@ constexpr int kFixupBlocks = 2048;
 // Outputs of the fully clamped run are not written here (one store per disparity plane and lane thrashes
 // the TLB): the run's value goes to `run_vals[f][h][d_first]` (NaN = keep the fast value) and
 // ncc_fixup_runs_kernel spreads it plane by plane.
+// A pattern window shared by all frames (single channel) is one item per group of kFixFrames frames: its own side
+// (window, mean, deviations) is staged once, the frames' rows follow one another with the next frame's rows already
+// on their way (register prefetch) -- the pass is latency-bound, a lone wavefront per item, and this takes the global
+// round trips of all but the first frame off its critical path.  Same arithmetic, same order as the generic path.
+constexpr int kFixFrames = 2;
+constexpr int kFixSpanRegs = 20;       // prefetched SPAN elements per lane (bs * (bs + D - 1) <= 64 * 20)
+
 template <int BS>
-__global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+__device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                float* __restrict__ out, float* __restrict__ run_vals,
+                                                const float* __restrict__ best, float rank_eps,
+                                                unsigned* __restrict__ flags, unsigned* __restrict__ n_hard,
+                                                int64_t* __restrict__ hard_list, float* sF, float* sFq, float* sFv,
+                                                float* sS, float* sSq, int f_lo, int f_hi, int h, int col, bool run_item,
+                                                int H, int W, int D, int bs_rt, int lane) {
+  const int bs = BS > 0 ? BS : bs_rt;
+  const int half = bs / 2, span = bs + D - 1, taps = bs * bs;
+  const float n = (float)taps;
+  const long HW = (long)H * W;
+  const int span_col0 = col - half;
+  // the lane's SPAN element offsets inside a frame (the same for every frame) and the first frame's elements
+  float pre[kFixSpanRegs];
+  int soff[kFixSpanRegs];
+#pragma unroll
+  for (int k = 0; k < kFixSpanRegs; ++k) {
+    const int i = min(lane + 64 * k, bs * span - 1);
+    const int bh = i / span, cc = i - bh * span;
+    soff[k] = clampi(h + bh - half, 0, H - 1) * W + clampi(span_col0 + cc, 0, W - 1);
+    pre[k] = in0[(long)f_lo * HW + soff[k]];
+  }
+  // FIX side: the pattern window, its mean (every tap divided before the sum, as the reference does) and deviations
+  for (int i0 = lane; i0 < taps; i0 += 64 * 2) {
+    float t[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = min(i0 + 64 * u, taps - 1);
+      const int bh = i / bs, bw = i - bh * bs;
+      t[u] = in1[(long)clampi(h + bh - half, 0, H - 1) * W + clampi(col + bw - half, 0, W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (i0 + 64 * u < taps) {
+        sF[i0 + 64 * u] = t[u];
+        sFq[i0 + 64 * u] = t[u] / n;
+      }
+  }
+  float mu_f = 0.f;
+  for (int bh = 0; bh < bs; ++bh) {
+#pragma unroll
+    for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) mu_f += sFq[bh * BS + bw];
+    if (BS == 0)
+      for (int bw = 0; bw < bs; ++bw) mu_f += sFq[bh * bs + bw];
+  }
+  for (int i = lane; i < taps; i += 64) sFv[i] = sF[i] - mu_f;
+  float s_f = 0.f;
+  for (int bh = 0; bh < bs; ++bh) {
+#pragma unroll
+    for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) s_f += sFv[bh * BS + bw] * sFv[bh * BS + bw];
+    if (BS == 0)
+      for (int bw = 0; bw < bs; ++bw) s_f += sFv[bh * bs + bw] * sFv[bh * bs + bw];
+  }
+  const int rounds = (D + 127) / 128;
+  // ranked calls: contenders of the whole item are claimed and pushed at its end, all atomics in flight together
+  constexpr int kCand = kFixFrames * 2;
+  bool cand[kCand];
+  long cpix[kCand];
+#pragma unroll
+  for (int i = 0; i < kCand; ++i) { cand[i] = false; cpix[i] = 0; }
+  auto flush_candidates = [&]() {
+    if (!best) return;
+    bool tk[kCand];
+#pragma unroll
+    for (int i = 0; i < kCand; ++i) tk[i] = cand[i] && worklist_claim(flags, cpix[i]);
+    worklist_push_n<kCand>(tk, cpix, n_hard, hard_list);
+#pragma unroll
+    for (int i = 0; i < kCand; ++i) cand[i] = false;
+  };
+  for (int f = f_lo; f < f_hi; ++f) {
+    // this frame's rows come out of the prefetch registers; the next frame's are requested right away
+#pragma unroll
+    for (int k = 0; k < kFixSpanRegs; ++k)
+      if (lane + 64 * k < bs * span) {
+        sS[lane + 64 * k] = pre[k];
+        sSq[lane + 64 * k] = pre[k] / n;
+      }
+    if (f + 1 < f_hi) {
+#pragma unroll
+      for (int k = 0; k < kFixSpanRegs; ++k) pre[k] = in0[(long)(f + 1) * HW + soff[k]];
+    }
+    // two disparities per lane and pass (d, d + 64): two independent serial chains in flight -- a lone wavefront
+    // spends this loop waiting for its own LDS reads and dependent adds
+    for (int r = 0; r < rounds; ++r) {
+      int dd[2];
+      bool bad[2];
+      float val[2], mb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        dd[t] = r * 128 + 64 * t + lane;
+        const int w = col + dd[t];
+        bad[t] = dd[t] < D && w >= 0 && w < W;
+        val[t] = 0.f;
+        // the pixel's merged best score (ranked calls): requested now, needed after the exact evaluation
+        mb[t] = (best && bad[t]) ? best[((long)f * H + h) * W + w] : 0.f;
+      }
+      const int o0 = min(dd[0], D - 1), o1 = min(dd[1], D - 1);    // clamped: lanes past D read valid LDS, results unused
+      if (__any(bad[0] || bad[1])) {
+        float mu0 = 0.f, mu1 = 0.f;
+        for (int bh = 0; bh < bs; ++bh) {
+          const float* q0 = sSq + bh * span + o0;
+          const float* q1 = sSq + bh * span + o1;
+#pragma unroll
+          for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) { mu0 += q0[bw]; mu1 += q1[bw]; }
+          if (BS == 0)
+            for (int bw = 0; bw < bs; ++bw) { mu0 += q0[bw]; mu1 += q1[bw]; }
+        }
+        float ss0 = 0.f, ss1 = 0.f, dot0 = 0.f, dot1 = 0.f;
+        for (int bh = 0; bh < bs; ++bh) {
+          const float* x0 = sS + bh * span + o0;
+          const float* x1 = sS + bh * span + o1;
+          const float* vf = sFv + bh * bs;
+#pragma unroll
+          for (int bw = 0; bw < (BS > 0 ? BS : 0); ++bw) {
+            const float v0 = x0[bw] - mu0, v1 = x1[bw] - mu1;
+            dot0 += vf[bw] * v0;
+            ss0 += v0 * v0;
+            dot1 += vf[bw] * v1;
+            ss1 += v1 * v1;
+          }
+          if (BS == 0)
+            for (int bw = 0; bw < bs; ++bw) {
+              const float v0 = x0[bw] - mu0, v1 = x1[bw] - mu1;
+              dot0 += vf[bw] * v0;
+              ss0 += v0 * v0;
+              dot1 += vf[bw] * v1;
+              ss1 += v1 * v1;
+            }
+        }
+        val[0] = 0.f + dot0 / ncc_norm(s_f, ss0);            // "T val = 0; val += dot / norm" (ext.h:142,186)
+        val[1] = 0.f + dot1 / ncc_norm(s_f, ss1);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int d = dd[t], w = col + d;
+        if (run_item) {
+          if (d < D) run_vals[((long)f * H + h) * D + d] = bad[t] ? val[t] : __int_as_float(0x7fc00000);
+        } else if (bad[t]) {
+          if (out) out[((long)f * D + d) * HW + (long)h * W + w] = val[t];
+        }
+        if (best) {                                            // wave-uniform: ranked call
+          const bool contender = bad[t] && !(val[t] < mb[t] - rank_margin(rank_eps, mb[t]));   // (also a NaN best)
+          if (rounds == 1) {                                   // one slot per (frame of the item, t): flushed at the end
+#pragma unroll
+            for (int i = 0; i < kCand; ++i)
+              if (i == (f - f_lo) * 2 + t) { cand[i] = contender; cpix[i] = ((long)f * H + h) * W + w; }
+          } else {
+            const long pix = ((long)f * H + h) * W + w;
+            worklist_push(contender && worklist_claim(flags, pix), pix, n_hard, hard_list);
+          }
+        }
+      }
+    }
+  }
+  flush_candidates();
+}
+
+template <int BS>
+__global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         long in1_frame_stride, float* __restrict__ out,
                                                         const unsigned* __restrict__ counters,
                                                         const unsigned long long* __restrict__ list_a,
@@ -249,16 +414,25 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
   const long HW = (long)H * W;
   const unsigned n_a = counters[0], n_b = counters[1];
   const unsigned per_b = in1_frame_stride == 0 ? (unsigned)frames : 1u;   // a shared pattern window meets every frame
-  const unsigned n_items = n_a + n_b * per_b;
+  // single channel, shared pattern, SPAN small enough for the prefetch registers: kFixFrames frames per item
+  const bool grouped = per_b > 1u && C == 1 && bs * span <= 64 * kFixSpanRegs;
+  const unsigned groups = grouped ? (per_b + kFixFrames - 1) / kFixFrames : per_b;
+  const unsigned n_items = n_a + n_b * groups;
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
   const int rounds = (D + 63) / 64;
   for (unsigned item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < n_items; item += n_waves) {
     const bool is_a = item < n_a;
-    const unsigned jb = is_a ? 0u : (item - n_a) / per_b;
+    const unsigned jb = is_a ? 0u : (item - n_a) / groups;
     const unsigned long long e = is_a ? list_a[item] : list_b[jb];
     const int z = (int)(e >> 40), h = (int)((e >> 20) & 0xFFFFF), col = (int)(e & 0xFFFFF) - 0x80000;
-    const int f = (is_a || per_b == 1u) ? z / C : (int)((item - n_a) - jb * per_b);
     const bool run_item = !is_a && col == -(bs - 1 - half);
+    if (grouped && !is_a) {
+      const int f_lo = (int)((item - n_a) - jb * groups) * kFixFrames;
+      fixup_grouped_item<BS>(in0, in1, out, run_vals, best, rank_eps, flags, n_hard, hard_list, sF, sFq, sFv, sS, sSq,
+                             f_lo, min(frames, f_lo + kFixFrames), h, col, run_item, H, W, D, bs, lane);
+      continue;
+    }
+    const int f = (is_a || per_b == 1u) ? z / C : (int)((item - n_a) - jb * groups);
     const float* fix_img = is_a ? in0 + (long)f * C * HW : in1 + (long)f * in1_frame_stride;
     const float* span_img = is_a ? in1 + (long)f * in1_frame_stride : in0 + (long)f * C * HW;
     const int span_col0 = is_a ? col - half - (D - 1) : col - half;
@@ -270,6 +444,7 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
       // every output of a listed window is recomputed (the fast kernels wrote NaN there)
       const bool bad = d < D && w >= 0 && w < W;
       float val = 0.f;
+      const float mbest = (best && bad) ? best[((long)f * H + h) * W + w] : 0.f;   // ranked calls: needed at the end
       if (__any(bad)) {
         for (int c = 0; c < C; ++c) {
           if (staged_c != c) {
@@ -360,10 +535,7 @@ __global__ __launch_bounds__(256) void ncc_fixup_kernel(const float* __restrict_
       if (best) {                                            // wave-uniform: ranked call
         bool take = false;
         const long pix = ((long)f * H + h) * W + w;
-        if (bad) {
-          const float m = best[pix];
-          if (!(val < m - rank_margin(rank_eps, m))) take = worklist_claim(flags, pix);   // (also a NaN best)
-        }
+        if (bad && !(val < mbest - rank_margin(rank_eps, mbest))) take = worklist_claim(flags, pix);   // (also a NaN best)
         worklist_push(take, pix, n_hard, hard_list);
       }
     }
