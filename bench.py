@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--workload", default=None, choices=["config2", "config3"],
                     help="default: config2 at one GPU, config3 (adds the geometric loss and its all-gather) at more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed steps: no parity probe, no CPU baseline, no also_measured legs (what the profiling "
+                         "scripts run, so that per-kernel statistics hold the step's own launches only)")
     ap.add_argument("--no-parity-probe", action="store_true",
                     help="skip the untimed 1-frame parity probe (the profiling scripts do: its launches would be averaged "
                          "into the per-kernel statistics)")
@@ -237,6 +240,8 @@ def also_measured(te, L, frames, pat_lcn, args):
 
 def main():
     args = parse_args()
+    if args.headline_only:
+        args.no_parity_probe = args.no_cpu_baseline = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
@@ -382,7 +387,7 @@ def main():
         }
         if geo is not None and losses:
             out["config"]["loss_allgather"] = [float(v) for v in losses[-1].flatten().tolist()]
-        if world == 1 and args.algo == "fast":
+        if world == 1 and args.algo == "fast" and not args.headline_only:
             out["also_measured"] = also_measured(te, L, frames, pat_lcn, args)
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[:min(args.frames, 32)].cpu())

@@ -5,12 +5,13 @@
 #                                   set-up launches such as the one-image LCN of the pattern have another grid)
 #   <tag>_pmc_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE (KiB) per launch of the same launches, separate --pmc passes
 #   <tag>_bench_under_rocprof.json the bench line of the traced run
-# bench.py runs with --no-parity-probe: the probe's 1-frame launches of the same kernels would be averaged in.
+# bench.py runs with --headline-only: the parity probe's 1-frame launches and the also_measured legs (plain volume
+# kernel, volume-free path) would be averaged into the same kernels' rows.
 tag=${1:-round2}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --no-cpu-baseline --no-parity-probe"
+B="python bench.py --headline-only"
 # 1. kernel trace of the exact bench command (no PMC in this pass)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 20 --warmup 3 > $out/bench_under_rocprof.log 2>&1 || exit 1
 grep '^{"metric"' $out/bench_under_rocprof.log > $out/${tag}_bench_under_rocprof.json
