@@ -337,6 +337,16 @@ def main():
     import ctypes
     avg_ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n_launch = L.ctd_kernel_timing_collect(ctypes.byref(avg_ms), ctypes.byref(cols))
+    # run-to-run spread: two more regions of the same K steps (reported next to the headline one, never instead of it)
+    repeats = []
+    if not args.headline_only:
+        for _ in range(2):
+            barrier()
+            t_r = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            repeats.append((time.perf_counter() - t_r) / args.steps * 1e3)
 
     ranks_seen = 1
     if dist is not None:
@@ -363,6 +373,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeat_ms_per_step": repeats,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
