@@ -61,6 +61,7 @@ SIGNATURES = {
     "ctd_pattern_loss_multi_bwd_f32": (_c_int, [_c_int, _levels_p, _vp, _vp, _c_int, _c_float, _c_int, _vp]),
     "ctd_render_mesh_proj_f32": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp,
                                           _c_float, _c_float, _vp, _vp, _vp, _c_int, _vp]),
+    "ctd_render_mesh_f32": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp]),
     "ctd_nn_f32": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_nn_f64": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),
     "ctd_crosscheck": (_c_int, [_vp, _vp, _c_long, _c_long, _vp, _c_int, _vp]),

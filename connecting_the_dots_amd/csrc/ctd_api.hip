@@ -9,28 +9,34 @@ using namespace ctd;
 
 namespace ctd {
 // Bench instrumentation (ctd_kernel_timing_*): process-global, one bench thread (documented in the header).
+// The events come from a pool created when timing is switched on (no hipEventCreate between launches) and carry
+// hipEventDisableSystemFence: a default event makes the queue release to system scope at every record (an L2
+// write-back of whatever the previous kernel left dirty), which the un-instrumented path never pays.
 static bool g_timing = false;
 static int g_timing_columns = 0;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
+static std::vector<hipEvent_t> g_pool;                                   // free events
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;          // recorded (start, stop) pairs
 static hipEvent_t g_pending = nullptr;
+static hipEvent_t pool_get() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
+  return e;
+}
 bool timing_enabled() { return g_timing; }
 void timing_begin(hipStream_t stream) {
   if (!g_timing) return;
-  if (g_pending) {                                   // a launch failed between begin and end: do not leak its event
-    (void)hipEventDestroy(g_pending);
-    g_pending = nullptr;
-  }
-  if (hipEventCreate(&g_pending) != hipSuccess) { g_pending = nullptr; return; }
-  (void)hipEventRecord(g_pending, stream);
+  if (!g_pending) g_pending = pool_get();            // (a launch that failed between begin and end left its event here)
+  if (g_pending) (void)hipEventRecord(g_pending, stream);
 }
 void timing_end(hipStream_t stream, int columns) {
   if (!g_timing || !g_pending) return;
-  hipEvent_t stop;
-  if (hipEventCreate(&stop) != hipSuccess) {
-    (void)hipEventDestroy(g_pending);
-    g_pending = nullptr;
-    return;
-  }
+  hipEvent_t stop = pool_get();
+  if (!stop) return;
   (void)hipEventRecord(stop, stream);
   g_events.emplace_back(g_pending, stop);
   g_pending = nullptr;
@@ -44,8 +50,14 @@ int ctd_version(void) { return 1; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;
-  if (!g_timing && g_pending) {
-    (void)hipEventDestroy(g_pending);
+  if (g_timing) {                                    // fill the pool up front: enough for a default bench region
+    while (g_pool.size() < 128) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break;
+      g_pool.push_back(e);
+    }
+  } else if (g_pending) {
+    g_pool.push_back(g_pending);
     g_pending = nullptr;
   }
 }
@@ -59,8 +71,8 @@ int ctd_kernel_timing_collect(double* avg_ms, int* columns) {
       total += ms;
       ++n;
     }
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    g_pool.push_back(ev.first);
+    g_pool.push_back(ev.second);
   }
   g_events.clear();
   if (avg_ms) *avg_ms = n ? total / n : 0.0;
@@ -459,6 +471,19 @@ int ctd_render_mesh_proj_f32(const float* verts, const float* colors, int n_vert
   if (g.status) return g.status;
   return render_mesh_proj_f32(verts, colors, faces, n_faces, cam, cam_width, cam_height, proj, proj_width, proj_height,
                               shader, pattern, d_alpha, d_beta, depth, color, normal, (hipStream_t)stream);
+}
+
+int ctd_render_mesh_f32(const float* verts, const float* colors, const float* normals, int n_verts, const int* faces,
+                        int n_faces, const float* cam, int cam_width, int cam_height, const float* shader, float* depth,
+                        float* color, float* normal, int device, void* stream) {
+  if (n_verts < 0 || n_faces < 0 || cam_width <= 0 || cam_height <= 0 || (double)cam_width * cam_height * 3 >= 2147483648.0)
+    return CTD_ERR_INVALID_ARG;
+  if (!cam || !shader || (n_faces > 0 && (!verts || !faces))) return CTD_ERR_INVALID_ARG;
+  if (n_faces > 0 && ((color && !colors) || ((color || normal) && !normals))) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return render_mesh_f32(verts, colors, normals, faces, n_faces, cam, cam_width, cam_height, shader, depth, color, normal,
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -122,5 +122,8 @@ int render_mesh_proj_f32(const float* verts, const float* colors, const int* fac
                          int cam_w, int cam_h, const float* proj_p, int proj_w, int proj_h, const float* shader,
                          const float* pattern, float d_alpha, float d_beta, float* depth, float* color, float* normal,
                          hipStream_t stream);
+int render_mesh_f32(const float* verts, const float* colors, const float* normals, const int* faces, int n_faces,
+                    const float* cam_p, int cam_w, int cam_h, const float* shader, float* depth, float* color, float* normal,
+                    hipStream_t stream);
 
 }  // namespace ctd

@@ -108,6 +108,40 @@ __device__ inline bool ray_mesh(float (*tile)[4], const float* orig, const float
   return valid;
 }
 
+// vec_add(1.f, acc, lam_k, attr + face[k] * 3, acc) for the three corners (render.h:199-203 / 302-306)
+__device__ inline void bary_mix(const float* __restrict__ attr, const int* face, float tu, float tv, float tw, float* acc) {
+  acc[0] = acc[1] = acc[2] = 0.f;
+  const float bary[3] = {tu, tv, tw};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float* a = attr + (long)face[k] * 3;
+    acc[0] = 1.f * acc[0] + bary[k] * a[0];
+    acc[1] = 1.f * acc[1] + bary[k] * a[1];
+    acc[2] = 1.f * acc[2] + bary[k] * a[2];
+  }
+}
+
+// Shader::operator()(orig, sp, lp = orig, n) with sp = orig + t * dir: reflectance_phong, geometry.h:277-292
+__device__ inline float phong_at_camera(const float* orig, const float* dir, float t, const float* nrm, float ka, float kd,
+                                        float ks, float alpha) {
+  const float sp[3] = {1.f * orig[0] + t * dir[0], 1.f * orig[1] + t * dir[1], 1.f * orig[2] + t * dir[2]};
+  float l[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};       // light at the camera centre
+  normalize3(l, l);
+  const float two_ln = 2 * dot3(l, nrm);
+  float r[3] = {two_ln * nrm[0] + -1.f * l[0], two_ln * nrm[1] + -1.f * l[1], two_ln * nrm[2] + -1.f * l[2]};
+  normalize3(r, r);
+  float vv[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};
+  normalize3(vv, vv);
+  return ka + kd * dot3(l, nrm) + ks * powf(dot3(r, vv), alpha);
+}
+
+__device__ inline void camera_ray(const CamDev& cam, int h, int w, float* dir) {   // Camera::to_ray, render.h:52-60
+  const float u0 = (w - cam.px) / cam.fx, u1 = (h - cam.py) / cam.fy;
+  dir[0] = cam.R[0] * u0 + cam.R[3] * u1 + cam.R[6];
+  dir[1] = cam.R[1] * u0 + cam.R[4] * u1 + cam.R[7];
+  dir[2] = cam.R[2] * u0 + cam.R[5] * u1 + cam.R[8];
+}
+
 __global__ __launch_bounds__(256) void render_proj_kernel(const float* __restrict__ verts, const float* __restrict__ colors,
                                                           const int* __restrict__ faces, int n_faces, CamDev cam,
                                                           CamDev proj, float ka, float kd, float ks, float alpha,
@@ -120,12 +154,7 @@ __global__ __launch_bounds__(256) void render_proj_kernel(const float* __restric
   const int h = idx / cam.width, w = idx % cam.width;
   const float orig[3] = {cam.C[0], cam.C[1], cam.C[2]};
   float dir[3];
-  {                                                              // Camera::to_ray, render.h:52-60
-    const float u0 = (w - cam.px) / cam.fx, u1 = (h - cam.py) / cam.fy;
-    dir[0] = cam.R[0] * u0 + cam.R[3] * u1 + cam.R[6];
-    dir[1] = cam.R[1] * u0 + cam.R[4] * u1 + cam.R[7];
-    dir[2] = cam.R[2] * u0 + cam.R[5] * u1 + cam.R[8];
-  }
+  camera_ray(cam, h, w, dir);
   int face_idx = 0;
   float t, tu, tv;
   bool valid = ray_mesh(tile, orig, dir, in_img, verts, faces, n_faces, face_idx, t, tu, tv);
@@ -148,24 +177,9 @@ __global__ __launch_bounds__(256) void render_proj_kernel(const float* __restric
       cross3(e1, e2, nrm);
       normalize3(nrm, nrm);
       if (dot3(nrm, dir) > 0) { nrm[0] = nrm[0] * -1.f; nrm[1] = nrm[1] * -1.f; nrm[2] = nrm[2] * -1.f; }
-      float col[3] = {0.f, 0.f, 0.f};
-      const float bary[3] = {tu, tv, tw};
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float* cv = colors + (long)face[k] * 3;
-        col[0] = 1.f * col[0] + bary[k] * cv[0];
-        col[1] = 1.f * col[1] + bary[k] * cv[1];
-        col[2] = 1.f * col[2] + bary[k] * cv[2];
-      }
-      const float sp[3] = {1.f * orig[0] + t * dir[0], 1.f * orig[1] + t * dir[1], 1.f * orig[2] + t * dir[2]};
-      float l[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};       // light at the camera centre
-      normalize3(l, l);
-      const float two_ln = 2 * dot3(l, nrm);
-      float r[3] = {two_ln * nrm[0] + -1.f * l[0], two_ln * nrm[1] + -1.f * l[1], two_ln * nrm[2] + -1.f * l[2]};
-      normalize3(r, r);
-      float vv[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};
-      normalize3(vv, vv);
-      const float refl = ka + kd * dot3(l, nrm) + ks * powf(dot3(r, vv), alpha);
+      float col[3];
+      bary_mix(colors, face, tu, tv, tw, col);
+      const float refl = phong_at_camera(orig, dir, t, nrm, ka, kd, ks, alpha);
 #pragma unroll
       for (int k = 0; k < 3; ++k) normal[idx * 3 + k] = std_min(1.f, std_max(0.f, refl * col[k]));
     }
@@ -227,6 +241,64 @@ int render_mesh_proj_f32(const float* verts, const float* colors, const int* fac
   hipLaunchKernelGGL(render_proj_kernel, dim3((unsigned)ceil_div(n, 256L)), dim3(256), 0, stream, verts, colors, faces,
                      n_faces, cam, proj, shader[0], shader[1], shader[2], shader[3], pattern, d_alpha, d_beta, depth, color,
                      normal);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+// RenderMeshFunctor<float>::operator() (render.h:150-223): camera rays only; the normal buffer receives the
+// interpolated vertex normals (flipped towards the camera, not normalised), the colour buffer the Phong-shaded
+// interpolated vertex colours.  Buffers may be null like the reference's.
+__global__ __launch_bounds__(256) void render_mesh_kernel(const float* __restrict__ verts, const float* __restrict__ colors,
+                                                          const float* __restrict__ normals, const int* __restrict__ faces,
+                                                          int n_faces, CamDev cam, float ka, float kd, float ks, float alpha,
+                                                          float* __restrict__ depth, float* __restrict__ color,
+                                                          float* __restrict__ normal) {
+  __shared__ float tile[kFaceTile * 3][4];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_img = idx < cam.width * cam.height;
+  const int h = idx / cam.width, w = idx % cam.width;
+  const float orig[3] = {cam.C[0], cam.C[1], cam.C[2]};
+  float dir[3];
+  camera_ray(cam, h, w, dir);
+  int face_idx = 0;
+  float t, tu, tv;
+  const bool valid = ray_mesh(tile, orig, dir, in_img, verts, faces, n_faces, face_idx, t, tu, tv);
+  if (!in_img) return;
+  if (depth) depth[idx] = valid ? t : -1;
+  if (!valid) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (color) color[idx * 3 + k] = 0;
+      if (normal) normal[idx * 3 + k] = 0;
+    }
+    return;
+  }
+  if (!normal && !color) return;
+  const int* face = faces + (long)face_idx * 3;
+  const float tw = 1 - tu - tv;
+  float nrm[3];
+  bary_mix(normals, face, tu, tv, tw, nrm);
+  if (dot3(nrm, dir) > 0) { nrm[0] = nrm[0] * -1.f; nrm[1] = nrm[1] * -1.f; nrm[2] = nrm[2] * -1.f; }
+  if (normal) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) normal[idx * 3 + k] = nrm[k];
+  }
+  if (color) {
+    float col[3];
+    bary_mix(colors, face, tu, tv, tw, col);
+    const float refl = phong_at_camera(orig, dir, t, nrm, ka, kd, ks, alpha);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) color[idx * 3 + k] = std_min(1.f, std_max(0.f, refl * col[k]));
+  }
+}
+
+int render_mesh_f32(const float* verts, const float* colors, const float* normals, const int* faces, int n_faces,
+                    const float* cam_p, int cam_w, int cam_h, const float* shader, float* depth, float* color, float* normal,
+                    hipStream_t stream) {
+  const CamDev cam = make_cam(cam_p, cam_w, cam_h);
+  const long n = (long)cam_w * cam_h;
+  hipLaunchKernelGGL(render_mesh_kernel, dim3((unsigned)ceil_div(n, 256L)), dim3(256), 0, stream, verts, colors, normals,
+                     faces, n_faces, cam, shader[0], shader[1], shader[2], shader[3], depth, color, normal);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

@@ -9,9 +9,10 @@ Same class names and call signatures as the Cython module the data generator use
     r.mesh_proj(data, proj, pattern, d_alpha=0, d_beta=0.35)
     im, depth, ambient = r.color(), r.depth(), r.normal()
 
-numpy in, numpy out like the reference; `render_mesh_proj` below is the tensor-level call that keeps everything
-on the device.  Only the projector renderer the data pipeline needs is provided (`mesh_proj`); there is no CPU
-engine in this package (engine='cpu' raises: the CPU path lives on as the test oracle).
+numpy in, numpy out like the reference; `render_mesh_proj` / `render_mesh` below are the tensor-level calls that keep
+everything on the device.  Both renderers of the reference are provided (`mesh_proj`, the one the data pipeline
+uses, and the plain `mesh`); there is no CPU engine in this package (engine='cpu' raises: the CPU path lives on as
+the test oracle).
 """
 import numpy as np
 import torch
@@ -94,6 +95,27 @@ def render_mesh_proj(verts, colors, faces, cam, proj, shader, pattern, d_alpha=1
     return depth, color, normal
 
 
+def render_mesh(verts, colors, normals, faces, cam, shader):
+    """RenderMeshFunctor (render.h:150-223): verts, colors, normals [n,3] f32, faces [m,3] int32 CUDA tensors ->
+    (depth [H,W], color [H,W,3], normal [H,W,3]) CUDA tensors."""
+    for t_, name, dt in ((verts, "verts", torch.float32), (colors, "colors", torch.float32),
+                         (normals, "normals", torch.float32), (faces, "faces", torch.int32)):
+        if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.is_contiguous() and t_.dtype == dt):
+            raise RuntimeError("%s must be a contiguous CUDA tensor of dtype %s" % (name, dt))
+    if colors.shape != verts.shape or normals.shape != verts.shape:
+        raise RuntimeError("colors and normals must have one row per vertex")
+    dev = verts.device
+    depth = torch.empty((cam.height, cam.width), dtype=torch.float32, device=dev)
+    color = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=dev)
+    normal = torch.empty((cam.height, cam.width, 3), dtype=torch.float32, device=dev)
+    st = _lib.lib().ctd_render_mesh_f32(
+        verts.data_ptr(), colors.data_ptr(), normals.data_ptr(), verts.shape[0], faces.data_ptr(), faces.shape[0],
+        cam.params.ctypes.data, cam.width, cam.height, shader.params.ctypes.data, depth.data_ptr(), color.data_ptr(),
+        normal.data_ptr(), dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(st, "render_mesh")
+    return depth, color, normal
+
+
 class PyRenderer:
     def __init__(self, cam, shader, engine='gpu', n_threads=1, device=None):
         if engine != 'gpu':
@@ -114,6 +136,16 @@ class PyRenderer:
     def normal(self):
         return self.normal_buffer
 
+    def _store(self, d, c, n):
+        self.depth_buffer[...] = d.cpu().numpy()
+        self.color_buffer[...] = c.cpu().numpy()
+        self.normal_buffer[...] = n.cpu().numpy()
+
+    def mesh(self, input):
+        up = lambda a: torch.from_numpy(a).to(self.device)
+        self._store(*render_mesh(up(input.verts), up(input.colors), up(input.normals), up(input.faces), self.cam,
+                                 self.shader))
+
     def mesh_proj(self, input, proj, pattern, d_alpha=1, d_beta=0):
         pattern = np.ascontiguousarray(pattern, np.float32)
         if pattern.shape != (proj.height, proj.width, 3):
@@ -121,6 +153,4 @@ class PyRenderer:
         up = lambda a: torch.from_numpy(a).to(self.device)
         d, c, n = render_mesh_proj(up(input.verts), up(input.colors), up(input.faces), self.cam, proj, self.shader,
                                    up(pattern), d_alpha, d_beta)
-        self.depth_buffer[...] = d.cpu().numpy()
-        self.color_buffer[...] = c.cpu().numpy()
-        self.normal_buffer[...] = n.cpu().numpy()
+        self._store(d, c, n)

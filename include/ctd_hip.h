@@ -317,6 +317,18 @@ int ctd_render_mesh_proj_f32(const float* verts, const float* colors, int n_vert
                              const float* pattern, float d_alpha, float d_beta, float* depth,
                              float* color, float* normal, int device, void* stream);
 
+/* Replaces RendererGpu<float>::render_mesh -- functor RenderMeshFunctor renderer/render/render.h:150-223
+ * (Python: PyRenderer.mesh, renderer/cyrender.pyx:193-194): camera rays only.
+ *   normals [n_verts][3] f32: device (the reference interpolates the given vertex normals, unnormalised)
+ *   depth [H][W] (-1 where nothing is hit), color [H][W][3] = clamp(phong * interpolated vertex colour, 0, 1),
+ *   normal [H][W][3] = interpolated vertex normal flipped towards the camera; colour and normal are 0 where
+ *   nothing is hit.  Each of the three outputs may be NULL (skipped), as the reference's Buffer allows.
+ * Bit-identical to the reference CPU build (colour: when ks == 0, else up to powf's last bits). */
+int ctd_render_mesh_f32(const float* verts, const float* colors, const float* normals, int n_verts,
+                        const int* faces, int n_faces, const float* cam, int cam_width, int cam_height,
+                        const float* shader, float* depth, float* color, float* normal, int device,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

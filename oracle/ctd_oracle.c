@@ -356,3 +356,76 @@ int ctd_oracle_render_mesh_proj_f32(const float* verts, const float* colors, int
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------- *
+ * RenderMeshFunctor<float>::operator()   renderer/render/render.h:150-223: camera rays only.
+ *   normals [n_verts][3]: interpolated with the hit's barycentrics (not normalised), flipped towards the camera
+ *   -> depth (-1 = no hit), color = clamp(phong * interpolated vertex colour), normal; colour and normal are
+ *      zeroed where nothing is hit.  Any of the three outputs may be NULL.
+ * ------------------------------------------------------------------------- */
+int ctd_oracle_render_mesh_f32(const float* verts, const float* colors, const float* normals, int n_verts,
+                               const int* faces, int n_faces, const float* cam_p, int cam_w, int cam_h,
+                               const float* shader, float* depth, float* color, float* normal, int nthreads) {
+  ocam_t cam;
+  ocam_init(&cam, cam_p, cam_w, cam_h);
+  const float ka = shader[0], kd = shader[1], ks = shader[2], alpha = shader[3];
+  (void)n_verts; (void)nthreads;
+  int idx;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (idx = 0; idx < cam_w * cam_h; ++idx) {
+    const int h = idx / cam.width, w = idx % cam.width;
+    const float* orig = cam.C;
+    float dir[3];
+    {
+      const float u0 = (w - cam.px) / cam.fx, u1 = (h - cam.py) / cam.fy;
+      dir[0] = cam.R[0] * u0 + cam.R[3] * u1 + cam.R[6];
+      dir[1] = cam.R[1] * u0 + cam.R[4] * u1 + cam.R[7];
+      dir[2] = cam.R[2] * u0 + cam.R[5] * u1 + cam.R[8];
+    }
+    int face_idx = 0;
+    float t, tu, tv;
+    const int valid = oray_mesh(orig, dir, faces, n_faces, verts, &face_idx, &t, &tu, &tv);
+    if (depth) depth[idx] = valid ? t : -1;
+    if (!valid) {
+      for (int k = 0; k < 3; ++k) {
+        if (color) color[idx * 3 + k] = 0;
+        if (normal) normal[idx * 3 + k] = 0;
+      }
+      continue;
+    }
+    if (!normal && !color) continue;
+    const int* face = faces + face_idx * 3;
+    const float bary[3] = {tu, tv, 1 - tu - tv};
+    float norm[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) {                               /* render.h:190-193 */
+      const float* nv = normals + face[k] * 3;
+      norm[0] = 1.f * norm[0] + bary[k] * nv[0];
+      norm[1] = 1.f * norm[1] + bary[k] * nv[1];
+      norm[2] = 1.f * norm[2] + bary[k] * nv[2];
+    }
+    if (odot3(norm, dir) > 0) { norm[0] = norm[0] * -1.f; norm[1] = norm[1] * -1.f; norm[2] = norm[2] * -1.f; }
+    if (normal) for (int k = 0; k < 3; ++k) normal[idx * 3 + k] = norm[k];
+    if (color) {
+      float col[3] = {0.f, 0.f, 0.f};
+      for (int k = 0; k < 3; ++k) {
+        const float* cv = colors + face[k] * 3;
+        col[0] = 1.f * col[0] + bary[k] * cv[0];
+        col[1] = 1.f * col[1] + bary[k] * cv[1];
+        col[2] = 1.f * col[2] + bary[k] * cv[2];
+      }
+      float sp[3] = {1.f * orig[0] + t * dir[0], 1.f * orig[1] + t * dir[1], 1.f * orig[2] + t * dir[2]};
+      float l[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};   /* reflectance_phong, geometry.h:277-292 */
+      onormalize3(l, l);
+      const float two_ln = 2 * odot3(l, norm);
+      float r[3] = {two_ln * norm[0] + -1.f * l[0], two_ln * norm[1] + -1.f * l[1], two_ln * norm[2] + -1.f * l[2]};
+      onormalize3(r, r);
+      float v[3] = {orig[0] - sp[0], orig[1] - sp[1], orig[2] - sp[2]};
+      onormalize3(v, v);
+      const float refl = ka + kd * odot3(l, norm) + ks * powf(odot3(r, v), alpha);
+      for (int k = 0; k < 3; ++k) color[idx * 3 + k] = omin(1.f, omax(0.f, refl * col[k]));
+    }
+  }
+  return 0;
+}

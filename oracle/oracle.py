@@ -181,6 +181,26 @@ def _cam_params(K, R, t):
                                                 np.asarray(t).reshape(3)]).astype(np.float32))
 
 
+def render_mesh(verts, colors, normals, faces, cam, shader, nthreads=1, fn=None, **_unused):
+    """RenderMeshFunctor (renderer/render/render.h:150-223).  cam = (K, R, t, width, height) -> depth [H,W],
+    color [H,W,3], normal [H,W,3].  `fn`: the reference harness's entry point (same signature)."""
+    verts, colors, normals = _c(verts, np.float32), _c(colors, np.float32), _c(normals, np.float32)
+    faces = _c(faces, np.int32)
+    cp = _cam_params(*cam[:3])
+    W, H = int(cam[3]), int(cam[4])
+    depth = np.zeros((H, W), np.float32)
+    color = np.zeros((H, W, 3), np.float32)
+    normal = np.zeros((H, W, 3), np.float32)
+    sh = np.asarray(shader, np.float32)
+    if fn is None:
+        fn = lib().ctd_oracle_render_mesh_f32
+    fn.argtypes = [_vp, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int]
+    rc = fn(_p(verts), _p(colors), _p(normals), verts.shape[0], _p(faces), faces.shape[0], _p(cp), W, H, _p(sh), _p(depth),
+            _p(color), _p(normal), nthreads)
+    assert rc == 0
+    return depth, color, normal
+
+
 def render_mesh_proj(verts, colors, faces, cam, proj, shader, pattern, d_alpha, d_beta, nthreads=1, fn=None):
     """RenderProjectorFunctor (renderer/render/render.h:251-364).  cam / proj = (K [3,3], R [3,3], t [3], width,
     height); shader = (ka, kd, ks, alpha); pattern [ph, pw, 3] -> depth [H,W], color [H,W,3], normal [H,W,3]

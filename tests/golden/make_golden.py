@@ -330,6 +330,10 @@ def gen_render():
         sc["shader"] = shader
         d, c, n = ora.render_mesh_proj(**sc, fn=ref)
         out["depth_%d" % k], out["color_%d" % k], out["normal_%d" % k] = d, c, n
+        # RendererCpu<float>::render_mesh (render_cpu.cpp:12-15): the plain renderer on the same scenes
+        d, c, n = ora.render_mesh(normals=workloads.render_normals(sc, seed), fn=build_ref.load_render().ctd_ref_render_mesh,
+                                  **sc)
+        out["mesh_depth_%d" % k], out["mesh_color_%d" % k], out["mesh_normal_%d" % k] = d, c, n
     save("render", **out)
 
 

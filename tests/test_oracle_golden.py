@@ -152,3 +152,7 @@ def test_render_mesh_proj_bit_exact(oracle):
         assert np.array_equal(n, g["normal_%d" % k]), k
         if not wall:
             assert (d == -1).any() and (c[d == -1] == 0).all() and (n[d == -1] == 0).all()
+        # render.h:150-223 (plain mesh renderer) on the same scenes
+        md, mc, mn = oracle.render_mesh(normals=workloads.render_normals(sc, seed), nthreads=4, **sc)
+        assert np.array_equal(md, g["mesh_depth_%d" % k]) and np.array_equal(md, d), k
+        assert np.array_equal(mc, g["mesh_color_%d" % k]) and np.array_equal(mn, g["mesh_normal_%d" % k]), k

@@ -40,6 +40,52 @@ def test_golden(k):
         assert_close(n, g["normal_%d" % k], rtol=1e-5, atol=1e-6, what="ambient image")
 
 
+def run_mesh(sc, normals):
+    from connecting_the_dots_amd import renderer
+    K, R, t, W, H = sc["cam"]
+    cam = renderer.PyCamera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], R, t, W, H)
+    data = renderer.PyRenderInput(verts=sc["verts"], colors=sc["colors"], normals=normals, faces=sc["faces"])
+    r = renderer.PyRenderer(cam, renderer.PyShader(*sc["shader"]), engine='gpu')
+    r.mesh(data)
+    return r.depth(), r.color(), r.normal()
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_plain_mesh_golden(k):
+    """PyRenderer.mesh (RenderMeshFunctor, render.h:150-223) against the reference's RendererCpu<float>::render_mesh"""
+    seed, wall, shader = CASES[k]
+    sc = workloads.render_scene(seed, wall=wall)
+    sc["shader"] = shader
+    g = golden("render")
+    d, c, n = run_mesh(sc, workloads.render_normals(sc, seed))
+    assert np.array_equal(d, g["mesh_depth_%d" % k]), "depth"
+    assert np.array_equal(n, g["mesh_normal_%d" % k]), "interpolated normals"
+    if shader[2] == 0.0:
+        assert np.array_equal(c, g["mesh_color_%d" % k]), "shaded colour"
+    else:
+        assert_close(c, g["mesh_color_%d" % k], rtol=1e-5, atol=1e-6, what="shaded colour")
+
+
+def test_plain_mesh_vs_oracle_larger_mesh_and_null_buffers(oracle):
+    import torch
+    from connecting_the_dots_amd import _lib, renderer
+    sc = workloads.render_scene(11, H=120, W=160, n_boxes=40)
+    nrm = workloads.render_normals(sc, 11)
+    d, c, n = run_mesh(sc, nrm)
+    od, oc, on = oracle.render_mesh(normals=nrm, nthreads=8, **sc)
+    assert np.array_equal(d, od) and np.array_equal(c, oc) and np.array_equal(n, on)
+    # depth only (colour / normal buffers NULL, as the reference's Buffer allows)
+    K, R, t, W, H = sc["cam"]
+    cam = renderer.PyCamera(K[0, 0], K[1, 1], K[0, 2], K[1, 2], R, t, W, H)
+    sh = renderer.PyShader(*sc["shader"])
+    v, f = torch.from_numpy(sc["verts"]).cuda(), torch.from_numpy(sc["faces"]).cuda()
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    st = _lib.lib().ctd_render_mesh_f32(v.data_ptr(), None, None, v.shape[0], f.data_ptr(), f.shape[0], cam.params.ctypes.data,
+                                        W, H, sh.params.ctypes.data, depth.data_ptr(), None, None, 0,
+                                        torch.cuda.current_stream().cuda_stream)
+    assert st == 0 and np.array_equal(depth.cpu().numpy(), od)
+
+
 def test_vs_oracle_larger_mesh_and_api_errors(oracle):
     """more faces than one LDS tile (256), 120 x 160 image"""
     from connecting_the_dots_amd import renderer

@@ -92,6 +92,19 @@ def render_scene(seed, H=48, W=64, n_boxes=4, wall=True):
                 d_alpha=0.0, d_beta=0.35)
 
 
+def render_normals(sc, seed):
+    """per-vertex normals for the plain mesh renderer: the area-weighted face normals gathered per vertex plus a
+    seeded jitter, deliberately left unnormalised (the reference interpolates them as given)"""
+    v, f = sc["verts"].astype(np.float64), sc["faces"]
+    fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    n = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(n, f[:, k], fn)
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-9)
+    n += np.random.RandomState(seed).uniform(-0.2, 0.2, size=n.shape)
+    return n.astype(np.float32)
+
+
 def small_pose(rs):
     """a small seeded rigid motion (rotation by ~0.01 rad about a random axis, 2 cm translation)"""
     ax = rs.randn(3) * 0.01
