@@ -2,6 +2,7 @@
 // Argument validation lives here; kernels assume validated shapes.
 #include "ctd_internal.h"
 
+#include <deque>
 #include <utility>
 #include <vector>
 
@@ -14,13 +15,13 @@ namespace ctd {
 // write-back of whatever the previous kernel left dirty), which the un-instrumented path never pays.
 static bool g_timing = false;
 static int g_timing_columns = 0;
-static std::vector<hipEvent_t> g_pool;                                   // free events
+static std::deque<hipEvent_t> g_pool;                                    // free events, reused first-in first-out
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;          // recorded (start, stop) pairs
 static hipEvent_t g_pending = nullptr;
 static hipEvent_t pool_get() {
   if (!g_pool.empty()) {
-    hipEvent_t e = g_pool.back();
-    g_pool.pop_back();
+    hipEvent_t e = g_pool.front();
+    g_pool.pop_front();
     return e;
   }
   hipEvent_t e = nullptr;
@@ -50,12 +51,19 @@ int ctd_version(void) { return 1; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;
-  if (g_timing) {                                    // fill the pool up front: enough for a default bench region
+  if (g_timing) {
+    // fill the pool up front (enough for a default bench region) and record every new event once: the runtime
+    // allocates an event's signal at its first record, and that must not happen between the start event and the
+    // kernel it brackets
+    bool fresh = false;
     while (g_pool.size() < 128) {
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break;
+      (void)hipEventRecord(e, nullptr);
       g_pool.push_back(e);
+      fresh = true;
     }
+    if (fresh) (void)hipStreamSynchronize(nullptr);
   } else if (g_pending) {
     g_pool.push_back(g_pending);
     g_pending = nullptr;

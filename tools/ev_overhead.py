@@ -1,4 +1,5 @@
-"""How much do the kernel-timing events cost a bench step?  Alternates regions of K steps with the hooks on / off."""
+"""How much do the kernel-timing events cost a bench step?  Alternates regions of K steps with the hooks on / off,
+and with the previous step's outputs held while the next step runs (two volumes alternate) or dropped."""
 import ctypes
 import sys
 import time
@@ -26,15 +27,19 @@ for _ in range(20):
     step()
 torch.cuda.synchronize()
 for rep in range(3):
+  for keep in (1, 0):
     for hooks in (1, 0):
         L.ctd_kernel_timing_enable(hooks)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(20):
-            step()
+            if keep:
+                held = step()
+            else:
+                step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 20 * 1e3
         L.ctd_kernel_timing_enable(0)
         a, c = ctypes.c_double(0), ctypes.c_int(0)
         n = L.ctd_kernel_timing_collect(ctypes.byref(a), ctypes.byref(c))
-        print("hooks=%d  %.4f ms/step  kernel avg %.4f ms over %d" % (hooks, dt, a.value, n), flush=True)
+        print("keep=%d hooks=%d  %.4f ms/step  kernel avg %.4f ms over %d" % (keep, hooks, dt, a.value, n), flush=True)
