@@ -205,15 +205,16 @@ def also_measured(te, L, frames, pat_lcn, args):
     """SURVEY 8d asks for two more numbers next to the step: (i) the volume-materialising kernel alone (no ranking in
     its epilogue: what ctd_xcorrvol_f32 launches), priced against the same roofline, and (ii) the fused, volume-free
     LCN -> NCC -> argmax (nothing materialised; bytes are inputs + indices only, so no HBM roofline applies).  Timed
-    after the headline region, 10 repetitions each, same inputs."""
+    after the headline region, 20 repetitions each after 80 untimed ones, same inputs."""
     import ctypes
     import torch
     x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
-    for _ in range(2):
+    L.ctd_kernel_timing_enable(1)
+    for _ in range(80):                            # ~30 ms of the same work first: clocks (see the settle loop in main)
         te.xcorrvol_batch(x, pat_lcn, D, BS, algo="fast")
     torch.cuda.synchronize()
-    L.ctd_kernel_timing_enable(1)
-    for _ in range(10):
+    L.ctd_kernel_timing_collect(None, None)
+    for _ in range(20):
         te.xcorrvol_batch(x, pat_lcn, D, BS, algo="fast")
     torch.cuda.synchronize()
     L.ctd_kernel_timing_enable(0)
@@ -223,16 +224,16 @@ def also_measured(te, L, frames, pat_lcn, args):
     plain = {"kernel": "ncc_fast_t256_kernel (volume only)", "avg_launch_ms": ms.value, "launches": n,
              "achieved_GBs": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 if n else None,
              "frac_of_hbm_peak": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
-    for _ in range(3):
+    for _ in range(80):
         xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
         te.xcorrvol_argmax(xx, pat_lcn, D, BS)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(20):
         xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
         idx, _ = te.xcorrvol_argmax(xx, pat_lcn, D, BS)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 10
+    dt = (time.perf_counter() - t0) / 20
     fused = {"what": "LCN -> NCC -> argmax with reference indices, no volume materialised", "ms_per_step": dt * 1e3,
              "value": args.frames * H * W * D / dt / 1e6, "unit": "Mpix*disp/s"}
     return {"volume_kernel_alone": plain, "fused_volume_free": fused}

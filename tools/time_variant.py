@@ -8,8 +8,9 @@ from tests import workloads
 def run(path):
     from connecting_the_dots_amd import _lib
     _lib._lib = None
-    if path:
-        _lib.LIB_PATH = path
+    if not hasattr(_lib, "_IN_TREE"):
+        _lib._IN_TREE = _lib.LIB_PATH
+    _lib.LIB_PATH = path or _lib._IN_TREE
     from connecting_the_dots_amd import torchext as te
     L = _lib.lib()
     H, W, D, N = 432, 512, 128, 16
@@ -18,10 +19,11 @@ def run(path):
     x, _ = te.lcn(fr, 5, 0.05)
     p, _ = te.lcn(pat, 5, 0.05)
     p = p[0].contiguous()
-    for _ in range(5):
+    L.ctd_kernel_timing_enable(1)
+    for _ in range(100):                # ~50 ms of the same work before timing: the card's clocks need it
         te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
     torch.cuda.synchronize()
-    L.ctd_kernel_timing_enable(1)
+    L.ctd_kernel_timing_collect(None, None)
     t0 = time.perf_counter()
     for _ in range(20):
         te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
@@ -31,7 +33,11 @@ def run(path):
     ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
     L.ctd_kernel_timing_enable(1)
-    for _ in range(10):
+    for _ in range(60):
+        te.xcorrvol_batch(x, p, D, 9, algo="fast")
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_collect(None, None)
+    for _ in range(20):
         te.xcorrvol_batch(x, p, D, 9, algo="fast")
     torch.cuda.synchronize()
     L.ctd_kernel_timing_enable(0)
