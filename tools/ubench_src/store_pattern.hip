@@ -43,6 +43,34 @@ __global__ __launch_bounds__(512) void pattern_plain_kernel(float* out, int H, i
     }
 }
 
+
+// cache-policy variants of the same pattern (gfx950 store modifiers)
+template <int POLICY>
+__global__ __launch_bounds__(512) void pattern_policy_kernel(float* out, int H, int W, int D, int band_rows, int n_dg, int dg,
+                                                             int waves, int nd) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= waves) return;
+  const int f = blockIdx.z / n_dg, g = blockIdx.z % n_dg;
+  const int h_lo = blockIdx.y * band_rows, h_hi = min(h_lo + band_rows, H);
+  const int col = blockIdx.x * 256 + lane * 4;
+  const f32x4 v = {1.f, 2.f, 3.f, (float)wave};
+  for (int h = h_lo; h < h_hi; ++h)
+    for (int j = 0; j < nd; ++j) {
+      const int d = g * dg + wave * nd + j;
+      if (d >= D) continue;
+      float* p = out + (((long)f * D + d) * H + h) * W + col;
+      if (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+      if (POLICY == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 int main() {
   const int F = 16, D = 128, H = 432, W = 512;
   const long n = (long)F * D * H * W;
@@ -70,6 +98,15 @@ int main() {
       if (nt == 0) time(name, [&] { hipLaunchKernelGGL(pattern_kernel, grid, dim3(512), 0, 0, out, H, W, D, band_rows, n_dg, dg, c.waves, c.nd, 1); });
       else time(name, [&] { hipLaunchKernelGGL(pattern_plain_kernel, grid, dim3(512), 0, 0, out, H, W, D, band_rows, n_dg, dg, c.waves, c.nd); });
     }
+  }
+
+  {
+    const int waves = 7, nd = 2, bands = 10, dg = 14, n_dg = 10, band_rows = 44;
+    dim3 grid(W / 256, bands, F * n_dg);
+    const char* names[8] = {"(none)", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
+#define RUN(P) { char name[128]; snprintf(name, sizeof name, "policy %-12s 7 waves 10 bands", names[P]); \
+    time(name, [&] { hipLaunchKernelGGL(pattern_policy_kernel<P>, grid, dim3(512), 0, 0, out, H, W, D, band_rows, n_dg, dg, waves, nd); }); }
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
   }
   for (int wgs : {2560, 3200, 8192, 32768}) {
     char name[128];
