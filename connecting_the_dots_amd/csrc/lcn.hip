@@ -18,7 +18,8 @@ namespace ctd {
 
 constexpr int kLcnTW = 64;
 constexpr int kLcnTH = 16;
-constexpr int kLcnRows = 4;   // block = 64 x 4 threads, each thread owns kLcnTH / 4 output rows
+constexpr int kLcnRows = 4;   // block = 64 x 4 threads, each thread owns kLcnTH / 4 CONSECUTIVE output rows
+constexpr int kLcnHC = 8;     // output columns per item of the horizontal pass
 
 __device__ inline int reflect_idx(int i, int n) {
   if (i < 0) i = -i;
@@ -26,7 +27,9 @@ __device__ inline int reflect_idx(int i, int n) {
   return i;
 }
 
-// R > 0: compile-time radius (tap loops unrolled, LDS reads pipelined); R == 0: run-time `radius_rt`
+// R > 0: compile-time radius (tap loops unrolled, LDS reads pipelined); R == 0: run-time `radius_rt`.
+// Both separable passes give a thread several adjacent outputs, so that the f32 -> f64 conversions, the squares and
+// the LDS reads of the taps they share happen once: every output is still its own ascending sum from 0 (same bits).
 template <int R>
 __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                float* __restrict__ stds, int H, int W, int radius_rt,
@@ -63,44 +66,79 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
   }
   __syncthreads();
 
-  for (int r = ty; r < TRr; r += kLcnRows) {
-    const float* row = tile + r * TCc + tx;
-    double s1 = 0, s2 = 0;
+  if (R > 0) {
+    // item = (staged row, chunk of kLcnHC output columns): kLcnHC + 2R taps converted once, kLcnHC sums each
+    constexpr int NT = kLcnHC + 2 * (R > 0 ? R : 1);
+    constexpr int CH = kLcnTW / kLcnHC;
+    for (int it = tid; it < TRr * CH; it += kLcnTW * kLcnRows) {
+      const int r = it / CH, c0 = (it - r * CH) * kLcnHC;
+      const float* row = tile + r * TCc + c0;
+      double v1[NT], v2[NT];
 #pragma unroll
-    for (int k = 0; k < (R > 0 ? 2 * R + 1 : 0); ++k) {
-      float v = row[k];
-      float v2 = v * v;                       // data**2 is an f32 tensor (networks.py:528)
-      s1 += (double)v;
-      s2 += (double)v2;
+      for (int k = 0; k < NT; ++k) {
+        const float v = row[k];
+        const float q = v * v;                // data**2 is an f32 tensor (networks.py:528)
+        v1[k] = (double)v;
+        v2[k] = (double)q;
+      }
+#pragma unroll
+      for (int o = 0; o < kLcnHC; ++o) {
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+          s1 += v1[o + k];
+          s2 += v2[o + k];
+        }
+        rs1[r * kLcnTW + c0 + o] = s1;
+        rs2[r * kLcnTW + c0 + o] = s2;
+      }
     }
-    if (R == 0)
+  } else {
+    for (int r = ty; r < TRr; r += kLcnRows) {
+      const float* row = tile + r * TCc + tx;
+      double s1 = 0, s2 = 0;
       for (int k = 0; k <= 2 * radius; ++k) {
         float v = row[k];
         float v2 = v * v;
         s1 += (double)v;
         s2 += (double)v2;
       }
-    rs1[r * kLcnTW + tx] = s1;
-    rs2[r * kLcnTW + tx] = s2;
+      rs1[r * kLcnTW + tx] = s1;
+      rs2[r * kLcnTW + tx] = s2;
+    }
   }
   __syncthreads();
 
   const int w = w_lo + tx;
   const float cnt = (float)((2 * radius + 1) * (2 * radius + 1));
-  for (int r = ty; r < kLcnTH; r += kLcnRows) {
-    const int h = h_lo + r;
-    if (w >= W || h >= H) continue;
-    double s1 = 0, s2 = 0;
+  constexpr int RPT = kLcnTH / kLcnRows;     // consecutive output rows of a thread
+  constexpr int NV = RPT + 2 * (R > 0 ? R : 0);
+  double c1[R > 0 ? NV : 1], c2[R > 0 ? NV : 1];
+  if (R > 0) {
 #pragma unroll
-    for (int k = 0; k < (R > 0 ? 2 * R + 1 : 0); ++k) {
-      s1 += rs1[(r + k) * kLcnTW + tx];
-      s2 += rs2[(r + k) * kLcnTW + tx];
+    for (int k = 0; k < NV; ++k) {
+      c1[k] = rs1[(ty * RPT + k) * kLcnTW + tx];
+      c2[k] = rs2[(ty * RPT + k) * kLcnTW + tx];
     }
-    if (R == 0)
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = ty * RPT + i;
+    const int h = h_lo + r;
+    double s1 = 0, s2 = 0;
+    if (R > 0) {
+#pragma unroll
+      for (int k = 0; k < 2 * R + 1; ++k) {
+        s1 += c1[i + k];
+        s2 += c2[i + k];
+      }
+    } else {
       for (int k = 0; k <= 2 * radius; ++k) {
         s1 += rs1[(r + k) * kLcnTW + tx];
         s2 += rs2[(r + k) * kLcnTW + tx];
       }
+    }
+    if (w >= W || h >= H) continue;
     float boxs = (float)s1, boxs2 = (float)s2;
     float avgs = boxs / cnt;
     float var = boxs2 / cnt - avgs * avgs + 1e-6f;
