@@ -1478,8 +1478,9 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
                   if (d - TAIL - i - w_lo > (int)l4) key[j][i] = -INFINITY;
               }
             } else {
+              // (volatile: as plain assignments the compiler runs these four moves on EVERY row, ahead of the branch)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) key[j][i] = -INFINITY;
+              for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0xff800000" : "=v"(key[j][i]));
             }
           }
         }
@@ -1497,8 +1498,11 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       } else {
         prefetch_next();
         if constexpr (RANK) {
+          // only the returned old top is reset: the next rank_second() then offers min(hi, lo) of the last output row
+          // once more -- a genuine non-top key of that pixel, harmless -- instead of twelve moves that the compiler
+          // runs on EVERY row, ahead of the branch (resetting all three), or ten spilled registers (resetting none)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
+          for (int i = 0; i < 4; ++i) rk_old[i] = -INFINITY;
         }
       }
       if (last_of_chunk) {
