@@ -542,10 +542,12 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
   }
 }
 
-// Second half of the run items: one workgroup per (frame, disparity plane) copies, for every listed fully
-// clamped pattern window (row h, from `run_rows`), the run values of the pixels w <= d - tail whose run has
-// started (first disparity w + tail <= d) into its plane -- all stores of a workgroup land in one plane,
-// (row, w) pairs are flattened over the threads so that every thread has independent loads in flight.
+// Second half of the run items: a workgroup per (frame, group of kRunPlanes disparity planes, quarter of the rows)
+// copies, for every listed fully clamped pattern window (row h, from `run_rows`), the run values of the pixels
+// w <= d - tail whose run has started (first disparity w + tail <= d) into the planes of its group -- (row, w) pairs
+// are flattened over the threads so that every thread has independent loads in flight.
+constexpr int kRunPlanes = 4;
+
 __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__ out, const float* __restrict__ run_vals,
                                                              const unsigned* __restrict__ counters,
                                                              const unsigned long long* __restrict__ run_rows, int per_frame,
@@ -554,20 +556,25 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   extern __shared__ int s_rows[];                          // up to C * H rows of this frame's pattern
   __shared__ int s_n;
   const int tid = threadIdx.x;
-  const int f = blockIdx.x / D, d = blockIdx.x - f * D;
+  // a workgroup serves kRunPlanes consecutive disparity planes of one frame: the list scan and the loads of the run
+  // values (the same for every plane, only the run gets longer) are paid once for all of them -- the pass is a chain
+  // of dependent global round trips per workgroup, not bandwidth
+  const int n_pg = (D + kRunPlanes - 1) / kRunPlanes;
+  const int f = blockIdx.x / n_pg, d0 = (blockIdx.x - f * n_pg) * kRunPlanes;
+  const int d1 = min(d0 + kRunPlanes, D) - 1;              // last plane of the group
   const int tail = bs - 1 - bs / 2;
-  const int seg = min(d - tail + 1, W);                    // pixels w in [0, d - tail]
+  const int seg_max = min(d1 - tail + 1, W);               // plane d: pixels w in [0, d - tail]
   // the work-list counter of the ranking pass that may follow (argmax_rerank.hip) lives at the start of the
   // workspace, which the volume kernel is done with by now: cleared here instead of by a memset of its own
   if (rank_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *rank_counter = 0u;
   const unsigned n_r = counters[2];
-  if (seg <= 0 || n_r == 0) return;
+  if (seg_max <= 0 || n_r == 0) return;
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (unsigned j = tid; j < n_r; j += blockDim.x) {
     const unsigned long long e = run_rows[j];
     const int z = (int)(e >> 20), h = (int)(e & 0xFFFFF);
-    // rows are dealt to the gridDim.y workgroups of a plane by h (late planes carry ~D pixels per row)
+    // rows are dealt to the gridDim.y workgroups of a plane group by h (late planes carry ~D pixels per row)
     if ((!per_frame || z / C == f) && h % (int)gridDim.y == (int)blockIdx.y) s_rows[atomicAdd(&s_n, 1)] = h;
   }
   __syncthreads();
@@ -576,9 +583,8 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   // accesses wherever the quad lies inside the run and the row starts are 16-byte aligned
   const int wq = tid & 31, rs = tid >> 5;
   const bool vec_ok = (D % 4 == 0) && (W % 4 == 0) && (tail % 4 == 0);
-  float* plane = out + ((long)f * D + d) * HW;
-  for (int w0 = 4 * wq; w0 < seg; w0 += 128) {
-    const bool full = vec_ok && w0 + 3 < seg;
+  for (int w0 = 4 * wq; w0 < seg_max; w0 += 128) {
+    const bool full_max = vec_ok && w0 + 3 < seg_max;
     for (int j0 = rs; j0 < s_n; j0 += 8 * 4) {
       f32x4 v[4];
       int hh[4];
@@ -587,24 +593,30 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
         const int j = min(j0 + 8 * u, s_n - 1);
         hh[u] = s_rows[j];
         const float* src = run_vals + ((long)f * H + hh[u]) * D + w0 + tail;
-        if (full) {
+        if (full_max) {
           v[u] = *(const f32x4*)src;
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[u][i] = w0 + i < seg ? src[i] : __int_as_float(0x7fc00000);
+          for (int i = 0; i < 4; ++i) v[u][i] = w0 + i < seg_max ? src[i] : __int_as_float(0x7fc00000);
         }
       }
+      for (int d = d0; d <= d1; ++d) {
+        const int seg = min(d - tail + 1, W);
+        if (w0 >= seg) continue;
+        const bool full = vec_ok && w0 + 3 < seg;
+        float* plane = out + ((long)f * D + d) * HW;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (j0 + 8 * u >= s_n) continue;
-        float* dst = plane + (long)hh[u] * W + w0;
-        const bool all_set = v[u][0] == v[u][0] && v[u][1] == v[u][1] && v[u][2] == v[u][2] && v[u][3] == v[u][3];
-        if (full && all_set) {
-          *(f32x4*)dst = v[u];
-        } else {
+        for (int u = 0; u < 4; ++u) {
+          if (j0 + 8 * u >= s_n) continue;
+          float* dst = plane + (long)hh[u] * W + w0;
+          const bool all_set = v[u][0] == v[u][0] && v[u][1] == v[u][1] && v[u][2] == v[u][2] && v[u][3] == v[u][3];
+          if (full && all_set) {
+            *(f32x4*)dst = v[u];
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (w0 + i < seg && v[u][i] == v[u][i]) dst[i] = v[u][i];
+            for (int i = 0; i < 4; ++i)
+              if (w0 + i < seg && v[u][i] == v[u][i]) dst[i] = v[u][i];
+          }
         }
       }
     }
@@ -1871,7 +1883,7 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
   if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   // (the old scan's work-list counter sits at the start of the workspace, which the volume kernel is done with by
   // now: cleared by the runs kernel instead of by a memset of its own)
-  hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * D), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
+  hipLaunchKernelGGL(ncc_fixup_runs_kernel, dim3((unsigned)(frames * ceil_div(D, kRunPlanes)), 4), dim3(256), lds_rows, stream, out, ws.run_vals,
                      ws.counters, ws.run_rows, per_frame ? 1 : 0, frames, C, H, W, D, bs, scan_counter);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
