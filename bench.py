@@ -285,7 +285,10 @@ def main():
         R, t = make_poses(args.frames, rank, device)
         half = args.frames // 2                                 # pairs (i, i + half): both halves are contiguous slices
         Ra, ta, Rb, tb = R[:half].contiguous(), t[:half].contiguous(), R[half:2 * half].contiguous(), t[half:2 * half].contiguous()
-    losses = []
+    # the loss exchange of config 3 is queued without stalling the compute stream (sharding.gather_scalars_async): a
+    # ring of four result buffers, each waited for (stream-level) when its slot comes round again and at the end
+    ring = [None] * 4
+    n_exchanged = [0]
 
     def step(exchange=True):
         x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
@@ -296,10 +299,13 @@ def main():
             depth = te.idx_to_depth(idx, FOCAL * BASELINE_M, 1.0).view(-1, 1, H, W)
             loss = geo(depth[:half], depth[half:2 * half], Ra, ta, Rb, tb)
             if exchange:
-                losses.append(sharding.gather_scalars(loss) if backend == "nccl" or dist is None
-                              else sharding.gather_scalars(loss.cpu()))
-                if len(losses) > 4:
-                    losses.pop(0)
+                k = n_exchanged[0] % len(ring)
+                if ring[k] is not None and ring[k][1] is not None:
+                    ring[k][1].wait()
+                src = loss if backend == "nccl" or dist is None else loss.cpu()
+                buf, work = sharding.gather_scalars_async(src, out=None if ring[k] is None or dist is None else ring[k][0])
+                ring[k] = (buf, work, src)
+                n_exchanged[0] += 1
         return x, idx, vol
 
     def barrier():
@@ -413,14 +419,20 @@ def main():
                 "traffic": measured_traffic(kernel),
             },
         }
-        if geo is not None and losses:
-            out["config"]["loss_allgather"] = [float(v) for v in losses[-1].flatten().tolist()]
+        if geo is not None and n_exchanged[0]:
+            last = ring[(n_exchanged[0] - 1) % len(ring)]
+            if last[1] is not None:
+                last[1].wait()
+            out["config"]["loss_allgather"] = [float(v) for v in last[0].flatten().tolist()]
         if world == 1 and args.algo == "fast" and not args.headline_only:
             out["also_measured"] = also_measured(te, L, frames, pat_lcn, args)
         if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(pat_lcn.cpu(), x[:min(args.frames, 32)].cpu())
         print(json.dumps(out), flush=True)
     if dist is not None:
+        for slot in ring:                                          # no exchange left in flight at tear-down
+            if slot is not None and slot[1] is not None:
+                slot[1].wait()
         dist.barrier()
         dist.destroy_process_group()
 

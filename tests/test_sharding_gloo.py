@@ -31,6 +31,11 @@ def _worker(rank, world, port, q):
     per_rank_mean = diff[b:e].mean()
     gm = sharding.reduce_mean(per_rank_mean, (e - b) * 20)
     gathered = sharding.gather_scalars(per_rank_mean)
+    # the non-blocking form (bench.py's config-3 step): same values once waited for, into a caller-owned buffer
+    buf = torch.full((world,), -1.0, dtype=per_rank_mean.dtype)
+    out_async, work = sharding.gather_scalars_async(per_rank_mean, out=buf)
+    work.wait()
+    assert out_async is buf and torch.equal(buf, gathered)
     q.put((rank, (b, e), float(val), float(full), float((d_local.grad - grad_full).abs().max()), float(gm),
            float(diff.mean()), gathered.tolist()))
     dist.barrier()
