@@ -25,9 +25,7 @@ constexpr int kScanBatch = 8;
 template <int PX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void argmax_scan_kernel(const float* __restrict__ vol, int64_t* __restrict__ idx,
                                                           float* __restrict__ best, int D, long HW, int W,
-                                                          int bs, float eps, long total_threads,
-                                                          unsigned* __restrict__ n_hard,
-                                                          int64_t* __restrict__ hard_list) {
+                                                          int bs, float eps, long total_threads, WorkList work) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_threads) return;
   const long p0 = t * PX;                         // first pixel (flat over frames); HW % 4 == 0 when VEC4
@@ -92,7 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const bool hard = v1[k] >= v0[k] - eps;
     idx[p0 + k] = hard ? (int64_t)(-1 - i0[k]) : (int64_t)i0[k];
     if (best) best[p0 + k] = v0[k];
-    if (hard) hard_list[atomicAdd(n_hard, 1u)] = p0 + k;   // rare (a few pixels in 10^4): pass 2's work list
+    if (hard) work.list[atomicAdd(work.counters, 1u)] = p0 + k;   // rare (a few pixels in 10^4): pass 2's work list
   }
 }
 
@@ -106,8 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, int n_dg, int dg_size,
                                                          unsigned char* __restrict__ flags,
                                                          int64_t* __restrict__ idx, float* __restrict__ best, long HW,
-                                                         float eps, long total_quads, unsigned* __restrict__ n_hard,
-                                                         int64_t* __restrict__ hard_list) {
+                                                         float eps, long total_quads, WorkList work) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total_quads) return;
@@ -145,7 +142,7 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict
     const bool hard = eps >= 0.f && (close || R[k] >= m - rank_margin(eps, m) || !(m > -INFINITY));
     idx[p0 + k] = gi[k] * dg_size + 15 - (__float_as_int(m) & 15);
     bq[k] = __int_as_float((__float_as_int(m) & ~31) | 16);     // centre of the truncation interval
-    worklist_push(hard, p0 + k, n_hard, hard_list);
+    worklist_push(hard, p0 + k, work);
     if (hard) listed4 |= 1u << (8 * k);
   }
   *(unsigned*)(flags + p0) = listed4;
@@ -171,9 +168,7 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
                                                              const float* __restrict__ in0,
                                                              const float* __restrict__ in1, long in1_frame_stride,
                                                              int64_t* __restrict__ idx, float* __restrict__ best,
-                                                             int D, int H, int W, int bs, float eps,
-                                                             const unsigned* __restrict__ n_hard,
-                                                             const int64_t* __restrict__ hard_list) {
+                                                             int D, int H, int W, int bs, float eps, WorkList work) {
   extern __shared__ float lds_resolve[];
   const int lane = threadIdx.x & 63;
   const int half = bs / 2, span = bs + D - 1;
@@ -185,10 +180,22 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
   float* sBq = sAq + bs * bs;
   const float bs2f = (float)(bs * bs);
   const long HW = (long)H * W;
-  const unsigned count = *n_hard;
+  // the list's segments, end to end (scalar: the counters are read once per wavefront)
+  unsigned seg_end[kWorkListParts];
+  unsigned count = 0;
+#pragma unroll
+  for (int k = 0; k < kWorkListParts; ++k) {
+    if (k < work.parts) count += work.counters[k * kWorkListStride];
+    seg_end[k] = count;
+  }
   const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
   for (unsigned item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); item < count; item += n_waves) {
-    const long pj = hard_list[item];                       // wave-uniform from here on
+    int seg = 0;
+    unsigned seg_begin = 0;
+#pragma unroll
+    for (int k = 0; k < kWorkListParts - 1; ++k)
+      if (item >= seg_end[k]) { seg = k + 1; seg_begin = seg_end[k]; }
+    const long pj = work.list[(long)seg * work.seg_cap + (item - seg_begin)];   // wave-uniform from here on
     const long fj = pj / HW, qj = pj - fj * HW;
     const int hj = (int)(qj / W), wj = (int)(qj - (long)hj * W);
     const float* v = VOL ? vol + fj * D * HW + qj : nullptr;
@@ -337,8 +344,8 @@ constexpr long kResolveBlocks = 1024;
 
 template <bool VOL>
 static int launch_resolve(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
-                          float* best, long total, int D, int H, int W, int bs, float eps, const unsigned* n_hard,
-                          const int64_t* hard_list, hipStream_t stream) {
+                          float* best, long total, int D, int H, int W, int bs, float eps, const WorkList& work,
+                          hipStream_t stream) {
   const size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
   if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
   const long chunks = (total + 255) / 256;
@@ -346,7 +353,7 @@ static int launch_resolve(const float* vol, const float* in0, const float* in1, 
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(resolve, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
-                     in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, n_hard, hard_list);
+                     in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -355,7 +362,7 @@ int rank_merge_f32(const RankPlan& rp, int64_t* idx, float* best, int frames, in
   if (D > kMaskWords * 64 || W % 4 != 0 || !best) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
   hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0, rp.n_dg,
-                     rp.dg_size, rp.flags, idx, best, (long)H * W, rp.eps, total / 4, rp.n_hard, rp.hard_list);
+                     rp.dg_size, rp.flags, idx, best, (long)H * W, rp.eps, total / 4, rp.work);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -364,10 +371,8 @@ int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, con
                      int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
   if (rp.eps < 0.f) return CTD_OK;                         // nothing is listed: plain argmax of the fast scores
   const long total = (long)frames * H * W;
-  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.n_hard,
-                                    rp.hard_list, stream)
-             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.n_hard,
-                                     rp.hard_list, stream);
+  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.work, stream)
+             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.work, stream);
 }
 
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
@@ -380,19 +385,19 @@ int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long
   // workspace by the time these kernels run on the same stream)
   if (!workspace || workspace_bytes < 16 + sizeof(int64_t) * (size_t)total) return CTD_ERR_WORKSPACE;
   unsigned* n_hard = (unsigned*)workspace;
-  int64_t* hard_list = (int64_t*)((char*)workspace + 16);
+  const WorkList work = {n_hard, (int64_t*)((char*)workspace + 16), 1, W, total};     // one plain list
   if (!counter_cleared) CTD_HIP_TRY(hipMemsetAsync(n_hard, 0, 16, stream));   // ncc_fixup_runs_kernel clears it
   const bool vec4 = W % 4 == 0 && ((uintptr_t)vol % 16) == 0;
   const int px = vec4 ? 4 : 1;
   if (px == 4)
     hipLaunchKernelGGL(argmax_scan_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, vol,
-                       idx, best, D, HW, W, bs, eps, total / 4, n_hard, hard_list);
+                       idx, best, D, HW, W, bs, eps, total / 4, work);
   else
     hipLaunchKernelGGL(argmax_scan_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, vol, idx,
-                       best, D, HW, W, bs, eps, total, n_hard, hard_list);
+                       best, D, HW, W, bs, eps, total, work);
   CTD_LAUNCH_CHECK();
   if (eps < 0.f) return CTD_OK;                            // nothing is marked: plain argmax of the fast volume
-  return launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, n_hard, hard_list, stream);
+  return launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, eps, work, stream);
 }
 
 }  // namespace ctd

@@ -47,4 +47,15 @@ __host__ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? l
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// work list of the ranked argmax (device helpers and the why: ctd_rank.h)
+constexpr int kWorkListStride = 64;            // unsigned between two counters
+constexpr int kWorkListParts = 16;
+struct WorkList {
+  unsigned* counters;                          // `parts` counters, kWorkListStride apart
+  int64_t* list;                               // `parts` segments of `seg_cap` entries
+  int parts;                                   // power of two (1: one plain list)
+  int row_width;                               // key = (pixel / row_width) & (parts - 1)
+  long seg_cap;
+};
+
 }  // namespace ctd

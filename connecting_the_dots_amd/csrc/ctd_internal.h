@@ -28,8 +28,8 @@ struct RankPlan {
                               // bits 0-3 = 15 - d % dg_size and bit 4 = "group's runner-up within the margin of its top"
   int n_dg, dg_size;          // disparity groups, disparities per group
   unsigned char* flags;       // [frames][H][W] 1 = pixel is on the work list (written by rank_merge_kernel)
-  unsigned* n_hard;           // work list of the pixels the exact re-scoring has to settle
-  int64_t* hard_list;
+  WorkList work;              // work list of the pixels the exact re-scoring has to settle (counters cleared by the
+                              // pre-pass kernel)
   float* best_scratch;        // [frames][H][W] merged best score when the caller does not ask for it
   size_t bytes;               // workspace bytes up to the end of these buffers
 };

@@ -77,7 +77,11 @@ struct PrepassJob {
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
 template <int BSC>
-__global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja, PrepassJob jb, int H, int W, int bs_rt) {
+__global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja, PrepassJob jb, int H, int W, int bs_rt,
+                                                                   unsigned* __restrict__ clear_counters, int n_clear) {
+  // the work-list counters of a ranked call (first used two kernels later): cleared here instead of by a memset launch
+  if (clear_counters && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)(threadIdx.y * kSTW + threadIdx.x) < n_clear)
+    clear_counters[(threadIdx.y * kSTW + threadIdx.x) * kWorkListStride] = 0u;
   const bool is_a = (int)blockIdx.z < ja.nimg;
   const PrepassJob& jp = is_a ? ja : jb;
   const int img_idx = is_a ? (int)blockIdx.z : (int)blockIdx.z - ja.nimg;
@@ -235,8 +239,8 @@ template <int BS>
 __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0, const float* __restrict__ in1,
                                                 float* __restrict__ out, float* __restrict__ run_vals,
                                                 const float* __restrict__ best, float rank_eps,
-                                                unsigned* __restrict__ flags, unsigned* __restrict__ n_hard,
-                                                int64_t* __restrict__ hard_list, float* sF, float* sFq, float* sFv,
+                                                unsigned* __restrict__ flags, WorkList work, float* sF, float* sFq,
+                                                float* sFv,
                                                 float* sS, float* sSq, int f_lo, int f_hi, int h, int col, bool run_item,
                                                 int H, int W, int D, int bs_rt, int lane) {
   const int bs = BS > 0 ? BS : bs_rt;
@@ -297,7 +301,9 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
     bool tk[kCand];
 #pragma unroll
     for (int i = 0; i < kCand; ++i) tk[i] = cand[i] && worklist_claim(flags, cpix[i]);
-    worklist_push_n<kCand>(tk, cpix, n_hard, hard_list);
+#pragma unroll
+    for (int g = 0; g < kFixFrames; ++g)                       // the two candidates of a frame lie in one image row
+      worklist_push2_same_row(tk[2 * g], cpix[2 * g], tk[2 * g + 1], cpix[2 * g + 1], work);
 #pragma unroll
     for (int i = 0; i < kCand; ++i) cand[i] = false;
   };
@@ -380,7 +386,7 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
               if (i == (f - f_lo) * 2 + t) { cand[i] = contender; cpix[i] = ((long)f * H + h) * W + w; }
           } else {
             const long pix = ((long)f * H + h) * W + w;
-            worklist_push(contender && worklist_claim(flags, pix), pix, n_hard, hard_list);
+            worklist_push(contender && worklist_claim(flags, pix), pix, work);
           }
         }
       }
@@ -397,8 +403,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
                                                         const unsigned long long* __restrict__ list_b,
                                                         float* __restrict__ run_vals,
                                                         const float* __restrict__ best, float rank_eps,
-                                                        unsigned* __restrict__ flags, unsigned* __restrict__ n_hard,
-                                                        int64_t* __restrict__ hard_list, int frames, int C, int H,
+                                                        unsigned* __restrict__ flags, WorkList work, int frames, int C, int H,
                                                         int W, int D, int bs_rt) {
   extern __shared__ float lds_fix[];
   const int bs = BS > 0 ? BS : bs_rt;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
     const bool run_item = !is_a && col == -(bs - 1 - half);
     if (grouped && !is_a) {
       const int f_lo = (int)((item - n_a) - jb * groups) * kFixFrames;
-      fixup_grouped_item<BS>(in0, in1, out, run_vals, best, rank_eps, flags, n_hard, hard_list, sF, sFq, sFv, sS, sSq,
+      fixup_grouped_item<BS>(in0, in1, out, run_vals, best, rank_eps, flags, work, sF, sFq, sFv, sS, sSq,
                              f_lo, min(frames, f_lo + kFixFrames), h, col, run_item, H, W, D, bs, lane);
       continue;
     }
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
         bool take = false;
         const long pix = ((long)f * H + h) * W + w;
         if (bad && !(val < mbest - rank_margin(rank_eps, mbest))) take = worklist_claim(flags, pix);   // (also a NaN best)
-        worklist_push(take, pix, n_hard, hard_list);
+        worklist_push(take, pix, work);
       }
     }
   }
@@ -1748,13 +1753,19 @@ static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, i
   rp.dg_size = kTDG;
   const size_t npart = align_up((size_t)frames * rp.n_dg * H * W * sizeof(float), 256);
   const size_t nflag = align_up((size_t)frames * H * W, 256);
-  const size_t nlist = align_up((size_t)frames * H * W * sizeof(int64_t), 256);
+  // work list: kWorkListParts segments keyed by image row, behind their counters (one cache line each)
+  const long seg_cap = (long)ceil_div(frames * H, kWorkListParts) * W;
+  const size_t ncnt = align_up(sizeof(unsigned) * kWorkListStride * kWorkListParts, 256);
+  const size_t nlist = ncnt + align_up((size_t)kWorkListParts * seg_cap * sizeof(int64_t), 256);
   char* p = (char*)base + offset;
   rp.k0 = (float*)p;
   rp.flags = (unsigned char*)(p + npart);
-  rp.hard_list = (int64_t*)(p + npart + nflag);
+  rp.work.counters = (unsigned*)(p + npart + nflag);
+  rp.work.list = (int64_t*)(p + npart + nflag + ncnt);
+  rp.work.parts = kWorkListParts;
+  rp.work.row_width = W;
+  rp.work.seg_cap = seg_cap;
   rp.best_scratch = (float*)(p + npart + nflag + nlist);
-  rp.n_hard = nullptr;                                             // lives with the volume pass's counters
   rp.bytes = offset + npart + nflag + nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
   return rp;
 }
@@ -1762,7 +1773,7 @@ static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, i
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off) {
   const FastWorkspace ws = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern);
   const RankPlan rp = rank_plan(nullptr, ws.bytes, frames, H, W, D);
-  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.flags; off[2] = (size_t)(ws.counters + 3); off[3] = (size_t)rp.hard_list;
+  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.flags; off[2] = (size_t)rp.work.counters; off[3] = (size_t)rp.work.list;
   off[4] = (size_t)rp.n_dg;
 }
 
@@ -1771,13 +1782,15 @@ size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_f
   return rank_plan(nullptr, off, frames, H, W, D).bytes;
 }
 
-static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int W, int bs, hipStream_t stream) {
+static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int W, int bs, const WorkList* work,
+                          hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
   const int w_out = ja.W_out > jb.W_out ? ja.W_out : jb.W_out;
   dim3 grid(ceil_div(w_out, kSTW), ceil_div(H, kSTH), ja.nimg + jb.nimg), block(kSTW, kSRows);
-  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, ja, jb, H, W, bs);
+  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, ja, jb, H, W, bs,
+                     work ? work->counters : nullptr, work ? work->parts : 0);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -1875,8 +1888,7 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
                      ws.flag_a, ws.flag_b, ws.run_vals, rank && rank->eps >= 0.f ? best : nullptr, rank ? rank->eps : -1.f,
-                     rank ? (unsigned*)rank->flags : nullptr, rank ? rank->n_hard : nullptr,
-                     rank ? rank->hard_list : nullptr, frames, C, H, W, D, bs);
+                     rank ? (unsigned*)rank->flags : nullptr, rank ? rank->work : WorkList{}, frames, C, H, W, D, bs);
   CTD_LAUNCH_CHECK();
   if (!out) return CTD_OK;                                   // nothing to spread without a volume
   const size_t lds_rows = sizeof(int) * (size_t)C * H;
@@ -1906,7 +1918,6 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
     const float eps = rank->eps;
     *rank = rank_plan(workspace, ws.bytes, frames, H, W, D);
     rank->eps = eps;
-    rank->n_hard = ws.counters + 3;                              // cleared with the other counters below
     need = rank->bytes;
   }
   if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
@@ -1918,7 +1929,7 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
                          nullptr, nullptr, -(double)(bs * bs)};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
                          ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0};
-  int st = launch_prepass(ja, jb, H, W, bs, stream);
+  int st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
   if (st) return st;
   switch (bs) {
     case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;

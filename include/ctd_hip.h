@@ -115,8 +115,9 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
  * -------------------------------------------------------------------------------------- */
 int ctd_xcorrvol_rank_supported(int C, int H, int W, int D, int block_size);
 /* Inspection aid for tests / tools: byte offsets, inside the workspace of a ranked ctd_xcorrvol_argmax_f32 call, of
- * offsets[0..3] = top-key plane ([frames][groups][H][W] f32), flag bytes [frames][H][W], the work-list counter (u32)
- * and the work list (i64 flat pixel indices); offsets[4] = number of disparity groups.  `offsets` has 5 entries. */
+ * offsets[0..3] = top-key plane ([frames][groups][H][W] f32), flag bytes [frames][H][W], the work-list counters (16 x
+ * u32, 256 bytes apart, one per key = image row & 15) and the work list (i64 flat pixel indices, 16 segments of
+ * ceil(frames * H / 16) * W entries, one per key); offsets[4] = number of disparity groups.  `offsets` has 5 entries. */
 int ctd_xcorrvol_rank_layout(int frames, int H, int W, int D, int per_frame_pattern, size_t* offsets);
 size_t ctd_xcorrvol_argmax_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo);
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,

@@ -21,10 +21,12 @@ assert st == 0, st
 torch.cuda.synchronize()
 off = (ctypes.c_size_t * 5)()
 L.ctd_xcorrvol_rank_layout(N, H, W, D, 0, off)
-n_hard = int(ws[off[2]:off[2] + 4].view(torch.int32).item())
+counts = [int(ws[off[2] + 256 * k:off[2] + 256 * k + 4].view(torch.int32).item()) for k in range(16)]
+n_hard = sum(counts)
+seg_cap = -(-N * H // 16) * W
 dirty = ws[off[1]:off[1] + N * H * W].view(N, H, W)
-print("pixels", N * H * W, "listed for re-scoring", n_hard, "flag bytes set", int(dirty.sum()))
-hl = ws[off[3]:off[3] + 8 * n_hard].view(torch.int64)
+print("pixels", N * H * W, "listed for re-scoring", n_hard, "per key", counts, "flag bytes set", int(dirty.sum()))
+hl = torch.cat([ws[off[3] + 8 * seg_cap * k:off[3] + 8 * (seg_cap * k + counts[k])].view(torch.int64) for k in range(16)])
 w = (hl % W).cpu().numpy(); h = ((hl // W) % H).cpu().numpy()
 print("listed by column: w<124:", int((w < 124).sum()), " w>=124:", int((w >= 124).sum()))
 # true top-2 gap statistics from the volume (run masked)
@@ -42,7 +44,7 @@ xoff = Dpad + 3
 W1 = align(W + 4 + xoff, 4); Wp = align(W + 8, 4)
 n0 = align(N * H * Wp * 4, 256); n1 = align(H * W1 * 4, 256)
 cnt = ws[3 * n0 + 3 * n1: 3 * n0 + 3 * n1 + 16].view(torch.int32).cpu().tolist()
-print("listed frame windows %d, listed pattern windows %d (of which run rows %d), work list %d" % tuple(cnt))
+print("listed frame windows %d, listed pattern windows %d (of which run rows %d)" % tuple(cnt[:3]))
 fl = ws[3 * n0 + 3 * n1 + 256 + align(N * H * W * 8, 256):][: 8 * cnt[1]].view(torch.int64).cpu().numpy()
 cols = (fl & 0xFFFFF) - 0x80000
 import collections
