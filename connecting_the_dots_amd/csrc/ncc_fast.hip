@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   unsigned long long* __restrict__ run_rows = jp.run_rows;
   if ((int)blockIdx.x * kSTW >= W_out) return;
   extern __shared__ double lds_d[];
-  __shared__ double cred[kSTW * kSRows];
+  __shared__ double cred[1];
   const int bs = BSC > 0 ? BSC : bs_rt;
   const int half = bs / 2;
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
@@ -107,13 +107,17 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kSTW + tx;
   const int xi_lo = blockIdx.x * kSTW, h_lo = blockIdx.y * kSTH;
   const float* img = in + (long)img_idx * frame_stride;          // image = frame * C + channel
-  {
+  // centring constant of the image = mean of its centre window: the first wavefront sums it with a fixed shuffle
+  // butterfly (the same bits in every workgroup), everyone else goes straight to the staging loads
+  if (tid < 64) {
     double t = 0;
-    for (int k = tid; k < bs * bs; k += kSTW * kSRows) {
+    for (int k = tid; k < bs * bs; k += 64) {
       int hh = clampi(H / 2 + k / bs - half, 0, H - 1), ww = clampi(W / 2 + k % bs - half, 0, W - 1);
       t += (double)img[(long)hh * W + ww];
     }
-    cred[tid] = t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (tid == 0) cred[0] = t;
   }
   // batches of independent loads: one memory round trip per 8 elements of a thread instead of one each
   for (int i0 = tid; i0 < TRr * TCc; i0 += kSTW * kSRows * 8) {
@@ -131,10 +135,6 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
       if (i0 + kSTW * kSRows * u < TRr * TCc) tile[i0 + kSTW * kSRows * u] = t[u];
   }
   __syncthreads();
-  for (int stride = kSTW * kSRows / 2; stride > 0; stride >>= 1) {   // fixed tree: same bits in every workgroup
-    if (tid < stride) cred[tid] += cred[tid + stride];
-    __syncthreads();
-  }
   const double n = (double)(bs * bs);
   const float cval = (float)(cred[0] / n);
   for (int r = ty; r < TRr; r += kSRows) {
