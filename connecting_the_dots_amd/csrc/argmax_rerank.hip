@@ -94,61 +94,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   }
 }
 
-// Merge of the per-group partials written by the volume kernel's in-kernel ranking (ncc_fast.hip, t256_consume):
-// 4 adjacent pixels per thread, one 16-byte load per disparity group.  A partial is the group's top score with
-// mantissa bits 0-3 = 15 - (disparity within the group) -- so the maximum carries its index -- and bit 4 = "the
-// group's runner-up lies within the re-ranking margin of its top".  A pixel whose runner-up (another group's top or
-// the flagged in-group one) lies within the margin of its best goes to the resolve pass (work list); its flag byte
-// says so.  Scores of listed windows (NaN in the volume kernel) are not in here: ncc_fast_fixup_ranked holds each of
-// them against the merged best afterwards and extends the work list.
-__global__ __launch_bounds__(256) void rank_merge_kernel(const float* __restrict__ k0, int n_dg, int dg_size,
-                                                         unsigned char* __restrict__ flags,
-                                                         int64_t* __restrict__ idx, float* __restrict__ best, long HW,
-                                                         float eps, long total_quads, WorkList work) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total_quads) return;
-  const long p0 = t * 4;
-  const long f = p0 / HW, q0 = p0 - f * HW;
-  const float* a0 = k0 + f * n_dg * HW + q0;
-  float M[4], R[4];
-  int gi[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { M[k] = -INFINITY; R[k] = -INFINITY; gi[k] = 0; }
-  constexpr int kB = 10;                                      // groups per batch of independent loads
-  for (int g0 = 0; g0 < n_dg; g0 += kB) {
-    f4 x0[kB];
-#pragma unroll
-    for (int u = 0; u < kB; ++u) x0[u] = __builtin_nontemporal_load((const f4*)(a0 + (long)min(g0 + u, n_dg - 1) * HW));
-#pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      if (g0 + u >= n_dg) break;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float top = x0[u][k];
-        R[k] = __builtin_amdgcn_fmed3f(M[k], R[k], top);        // second largest of the tops
-        gi[k] = top > M[k] ? g0 + u : gi[k];                    // strict >: the lower group keeps a tie
-        M[k] = fmaxf(M[k], top);
-      }
-    }
-  }
-  f4 bq;
-  unsigned listed4 = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float m = M[k];
-    const bool close = (__float_as_int(m) & 16) != 0;           // in-group runner-up within the margin (volume kernel)
-    // m == -inf: every score of the pixel was left to the fix-up pass
-    const bool hard = eps >= 0.f && (close || R[k] >= m - rank_margin(eps, m) || !(m > -INFINITY));
-    idx[p0 + k] = gi[k] * dg_size + 15 - (__float_as_int(m) & 15);
-    bq[k] = __int_as_float((__float_as_int(m) & ~31) | 16);     // centre of the truncation interval
-    worklist_push(hard, p0 + k, work);
-    if (hard) listed4 |= 1u << (8 * k);
-  }
-  *(unsigned*)(flags + p0) = listed4;
-  *(f4*)(best + p0) = bq;
-}
-
 // Pass 2: one wavefront per pixel of the work list.  VOL: lane <-> disparity collects the pixel's candidate set from
 // the (patched) fast volume with one round of loads (scores within eps of the best; the run of disparities whose
 // window is clamped to column 0 counted once, lowest d); a single candidate is final, otherwise the frame window
@@ -360,15 +305,6 @@ static int launch_resolve(const float* vol, const float* in0, const float* in1, 
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(resolve, dim3((unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks)), dim3(256), lds, stream, vol,
                      in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work);
-  CTD_LAUNCH_CHECK();
-  return CTD_OK;
-}
-
-int rank_merge_f32(const RankPlan& rp, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream) {
-  if (D > kMaskWords * 64 || W % 4 != 0 || !best) return CTD_ERR_UNSUPPORTED;
-  const long total = (long)frames * H * W;
-  hipLaunchKernelGGL(rank_merge_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, rp.k0, rp.n_dg,
-                     rp.dg_size, rp.flags, idx, best, (long)H * W, rp.eps, total / 4, rp.work);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

@@ -47,7 +47,7 @@ void timing_end(hipStream_t stream, int columns) {
 
 extern "C" {
 
-int ctd_version(void) { return 1; }
+int ctd_version(void) { return 2; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;
@@ -187,19 +187,22 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     return ncc_exact_argmax_f32(in0, in1, in1_frame_stride, vol_out, idx, best, frames, H, W, D, block_size, workspace,
                                 workspace_bytes, (hipStream_t)stream);
   if (algo == CTD_NCC_FAST) {
-    if (rerank_eps != rerank_eps) return CTD_ERR_INVALID_ARG;              // eps < 0 disables the re-rank
-    if (ncc_fast_rank_supported(1, H, W, D, block_size) && ((uintptr_t)vol_out) % 16 == 0) {
-      // ranked inside the volume kernel: partial top-2 per disparity group, merged here; no pass over the volume
+    if (rerank_eps != rerank_eps) return CTD_ERR_INVALID_ARG;
+    // rerank_eps < 0 (plain argmax of the fast scores, no exact re-scoring) is defined on a materialised volume: the
+    // scores of listed windows exist only there (fix-up pass), so such a call ranks the patched volume in one more pass
+    const bool plain = rerank_eps < 0.f && vol_out;
+    if (!plain && ncc_fast_rank_supported(1, H, W, D, block_size) && ((uintptr_t)vol_out) % 16 == 0) {
+      // ranked inside the all-D volume kernel: {top, runner-up} per pixel in LDS across every disparity; the kernel
+      // writes idx / best / work list itself -- no partial planes, no merge, no pass over the volume
       RankPlan rp;
-      rp.eps = rerank_eps;
+      rp.eps = rerank_eps < 0.f ? 0.f : rerank_eps;                        // (no volume: negative eps means 0)
+      rp.idx = idx;
+      rp.best = best;
       const hipStream_t hs = (hipStream_t)stream;
       int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
-                            workspace_bytes, &rp, hs);                 // pre-pass + volume kernel (writes the partials)
+                            workspace_bytes, &rp, hs);                 // pre-pass + all-D kernel
       if (st) return st;
-      float* b = best ? best : rp.best_scratch;
-      st = rank_merge_f32(rp, idx, b, frames, D, H, W, hs);
-      if (st) return st;
-      st = ncc_fast_fixup_ranked(in0, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, b, hs);
+      st = ncc_fast_fixup_ranked(in0, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, rp.best, hs);
       if (st) return st;
       return rank_resolve_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, hs);
     }

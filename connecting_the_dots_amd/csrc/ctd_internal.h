@@ -23,14 +23,13 @@ int argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames, int
 // ncc_fast.hip
 // Buffers of the in-kernel ranking (all inside the caller's workspace, laid out by ncc_fast_f32).
 struct RankPlan {
-  float eps;                  // in: re-ranking margin requested by the caller (< 0: none)
-  float* k0;                  // [frames][n_dg][H][W] top score KEY of every disparity group: the f32 score with mantissa
-                              // bits 0-3 = 15 - d % dg_size and bit 4 = "group's runner-up within the margin of its top"
-  int n_dg, dg_size;          // disparity groups, disparities per group
-  unsigned char* flags;       // [frames][H][W] 1 = pixel is on the work list (written by rank_merge_kernel)
+  float eps;                  // in: re-ranking margin requested by the caller
+  int64_t* idx;               // in: [frames][H][W] indices (written by the all-D kernel, corrected by the resolve pass)
+  float* best;                // in: [frames][H][W] best scores, or null (out: best_scratch then)
+  unsigned char* flags;       // [frames][H][W] 1 = pixel is on the work list (written by the all-D kernel)
   WorkList work;              // work list of the pixels the exact re-scoring has to settle (counters cleared by the
                               // pre-pass kernel)
-  float* best_scratch;        // [frames][H][W] merged best score when the caller does not ask for it
+  float* best_scratch;        // [frames][H][W] best score when the caller does not ask for it
   size_t bytes;               // workspace bytes up to the end of these buffers
 };
 size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
@@ -46,7 +45,6 @@ int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_str
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
                       size_t workspace_bytes, bool counter_cleared, hipStream_t stream);
-int rank_merge_f32(const RankPlan& rp, int64_t* idx, float* best, int frames, int D, int H, int W, hipStream_t stream);
 int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
                      int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream);
 

@@ -4,10 +4,13 @@
 
 namespace ctd {
 
-// Margin inside which two scores count as tied for the exact re-scoring: the caller's eps plus the truncation of two
-// keys (5 mantissa bits each: index tag + tie flag).  The volume kernel, the merge and the fix-up check use this one
-// expression.
-__device__ inline float rank_margin(float eps, float top) { return eps + 8e-6f * fmaxf(1.f, fabsf(top)); }
+// Margin inside which two scores count as tied for the exact re-scoring: the caller's eps plus the resolution of two
+// keys of the in-kernel ranking (fixed point, 2^-21 = 4.8e-7 absolute each way, ncc_fast.hip).  The all-D kernel and the
+// fix-up check use this one expression.
+__device__ inline float rank_margin(float eps, float top) {
+  (void)top;
+  return eps + 1e-6f;
+}
 
 // Work list of the pixels the exact re-scoring has to settle.  Atomics on ONE address retire one every ~7 ns on this
 // part -- two thousand list appends of the fix-up pass were a third of its time -- so the list comes in `parts`

@@ -56,7 +56,7 @@ constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
 constexpr double kDevFloor = 6e-3;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 3e-4 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
-// out_mean = mean_scale * (window mean - cval), out_dev = 1 / sqrt(sum of squared deviations) (NaN: listed window), out_img = img - cval
+// out_mean = mean_scale * (window mean - cval), out_dev = 1 / sqrt(sum of squared deviations) (0: listed window), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
 // cval = f64 window mean at the image centre, recomputed identically by every workgroup.
 // One launch serves the frames (job a) and the pattern (job b): blockIdx.z < a.nimg -> image blockIdx.z of job a,
@@ -179,8 +179,9 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     //  * (nearly) flat window, deviation below 2e-4 of its mean: the reference's own value is then decided by
     //    the rounding of its mean (ext.h:157-158) and only the same operation order reproduces it; or deviation
     //    below kDevFloor, where the 1e-8 of the reference's denominator stops being a small correction.
-    // A listed window's deviation is stored as NaN: the fast kernels then produce NaN for exactly the outputs the
-    // fix-up pass overwrites, and a NaN score never enters the in-kernel ranking (t256_consume).
+    // A listed window's reciprocal deviation is stored as 0: the fast kernels then produce the placeholder score 0 for
+    // exactly the outputs the fix-up pass overwrites (finite, so the in-kernel ranking's integer keys stay ordered;
+    // what the ranking does about placeholders: see the all-D kernel).
     const double mc = mean - (double)cval;
     const bool flat = 4e-8 * n * mean * mean > var || var < kDevFloor * kDevFloor;
     const bool listed = flat || n * mc * mc > kFlagRatio * var;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     const long o = ((long)img_idx * H + h) * W_out + xi;
     const int col = xi + x_start;
     out_mean[o] = (float)(jp.mean_scale * mc);
-    out_dev[o] = listed ? __int_as_float(0x7fc00000) : rdev;
+    out_dev[o] = listed ? 0.f : rdev;
     out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
     if (listed && col >= col_lo && col < col_hi) {
       flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)img_idx << 40) | ((unsigned long long)h << 20) |
@@ -217,10 +218,10 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
 //                             whole run d' >= d of pixel w = x + d (ext.h:152-154 makes the run constant).
 // The NCC is symmetric in the two windows (dot and sigma0*sigma1 commute exactly), so one staging layout
 // serves both cases.
-// Ranked calls (ncc_fast_fixup_ranked, after rank_merge_kernel): the in-kernel ranking never saw these scores (NaN),
-// so every recomputed one is held against the pixel's merged best; a pixel whose best is not clear of it by the
-// re-ranking margin joins the work list of the exact re-scoring (once: its flag byte is claimed atomically).  `out`
-// may be null then (nothing was materialised).
+// Ranked calls (ncc_fast_fixup_ranked, after the all-D kernel): the in-kernel ranking saw the placeholder score 0
+// instead of these, so every recomputed one is held against the pixel's best; a pixel whose best is not clear of it by
+// the re-ranking margin, or whose index IS the placeholder's disparity, joins the work list of the exact re-scoring
+// (once: its flag byte is claimed atomically).  `out` may be null then (nothing was materialised).
 constexpr int kFixupBlocks = 2048;
 
 // Loops over the window rows stay rolled (a fully unrolled body is ~40 KB of straight-line code that every
@@ -238,7 +239,8 @@ constexpr int kFixSpanRegs = 20;       // prefetched SPAN elements per lane (bs 
 template <int BS>
 __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0, const float* __restrict__ in1,
                                                 float* __restrict__ out, float* __restrict__ run_vals,
-                                                const float* __restrict__ best, float rank_eps,
+                                                const float* __restrict__ best, const int64_t* __restrict__ idx,
+                                                float rank_eps,
                                                 unsigned* __restrict__ flags, WorkList work, float* sF, float* sFq,
                                                 float* sFv,
                                                 float* sS, float* sSq, int f_lo, int f_hi, int h, int col, bool run_item,
@@ -325,14 +327,16 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
       int dd[2];
       bool bad[2];
       float val[2], mb[2];
+      bool won[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         dd[t] = r * 128 + 64 * t + lane;
         const int w = col + dd[t];
         bad[t] = dd[t] < D && w >= 0 && w < W;
         val[t] = 0.f;
-        // the pixel's merged best score (ranked calls): requested now, needed after the exact evaluation
+        // the pixel's best score and index (ranked calls): requested now, needed after the exact evaluation
         mb[t] = (best && bad[t]) ? best[((long)f * H + h) * W + w] : 0.f;
+        won[t] = best && bad[t] && idx[((long)f * H + h) * W + w] == (int64_t)dd[t];   // the placeholder came out on top
       }
       const int o0 = min(dd[0], D - 1), o1 = min(dd[1], D - 1);    // clamped: lanes past D read valid LDS, results unused
       if (__any(bad[0] || bad[1])) {
@@ -379,7 +383,7 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
           if (out) out[((long)f * D + d) * HW + (long)h * W + w] = val[t];
         }
         if (best) {                                            // wave-uniform: ranked call
-          const bool contender = bad[t] && !(val[t] < mb[t] - rank_margin(rank_eps, mb[t]));   // (also a NaN best)
+          const bool contender = bad[t] && (won[t] || !(val[t] < mb[t] - rank_margin(rank_eps, mb[t])));
           if (rounds == 1) {                                   // one slot per (frame of the item, t): flushed at the end
 #pragma unroll
             for (int i = 0; i < kCand; ++i)
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
                                                         const unsigned long long* __restrict__ list_a,
                                                         const unsigned long long* __restrict__ list_b,
                                                         float* __restrict__ run_vals,
-                                                        const float* __restrict__ best, float rank_eps,
+                                                        const float* __restrict__ best,
+                                                        const int64_t* __restrict__ idx, float rank_eps,
                                                         unsigned* __restrict__ flags, WorkList work, int frames, int C, int H,
                                                         int W, int D, int bs_rt) {
   extern __shared__ float lds_fix[];
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
     const bool run_item = !is_a && col == -(bs - 1 - half);
     if (grouped && !is_a) {
       const int f_lo = (int)((item - n_a) - jb * groups) * kFixFrames;
-      fixup_grouped_item<BS>(in0, in1, out, run_vals, best, rank_eps, flags, work, sF, sFq, sFv, sS, sSq,
+      fixup_grouped_item<BS>(in0, in1, out, run_vals, best, idx, rank_eps, flags, work, sF, sFq, sFv, sS, sSq,
                              f_lo, min(frames, f_lo + kFixFrames), h, col, run_item, H, W, D, bs, lane);
       continue;
     }
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
       const bool bad = d < D && w >= 0 && w < W;
       float val = 0.f;
       const float mbest = (best && bad) ? best[((long)f * H + h) * W + w] : 0.f;   // ranked calls: needed at the end
+      const bool won = best && bad && idx[((long)f * H + h) * W + w] == (int64_t)d;   // the placeholder came out on top
       if (__any(bad)) {
         for (int c = 0; c < C; ++c) {
           if (staged_c != c) {
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
       if (best) {                                            // wave-uniform: ranked call
         bool take = false;
         const long pix = ((long)f * H + h) * W + w;
-        if (bad && !(val < mbest - rank_margin(rank_eps, mbest))) take = worklist_claim(flags, pix);   // (also a NaN best)
+        if (bad && (won || !(val < mbest - rank_margin(rank_eps, mbest)))) take = worklist_claim(flags, pix);
         worklist_push(take, pix, work);
       }
     }
@@ -1198,57 +1204,14 @@ constexpr int kTBufs = 3;
 constexpr int kTDmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
 constexpr int kTOffB = 3 * kTA, kTOffH = 3 * kTA + 3 * kTSpanPad;
 
-// ---- in-kernel ranking (MODE & kRank) -------------------------------------------------------------------------
-// The argmax over disparity used to re-read the whole volume (1.8 GB at config 2).  With ranking on, the consumers
-// keep, per output pixel and per workgroup (kTDG disparities), the two largest scores and the disparity of the
-// largest: every score becomes a KEY = the f32 score with its 4 low mantissa bits replaced by 15 - (disparity within
-// the group), so that a plain float maximum carries the index along (relative truncation 2^-19; lower disparity wins
-// among equal truncated positive scores).  Per pixel two LDS slots {top, second} are fed with float atomics:
-//     old = ds_max_rtn_f32(top, hi);  ds_max_f32(second, med3(old, hi, lo))      (hi >= lo: the lane's two keys)
-// -- every key that is not the final maximum is, at some point, the loser of such an exchange, so `second` ends up as
-// the runner-up.  The second atomic of a row is issued at the start of the next row (its operand is the first one's
-// return value).  Slots form a ring of three chunks: the rows of chunk k are complete at the barrier that ends chunk
-// k + 1 and are read out (and reset) by one consumer wavefront per row during chunk k + 2, under the barriers the
-// pipeline already has.  What leaves the kernel is ONE f32 word per pixel and group, [frames][n_dgroups][H][W]
-// (4 B instead of kTDG * 4 B): the top key with mantissa bit 4 replaced by "the group's runner-up lies within the
-// re-ranking margin of its top" -- all the merge needs to know about it.  rank_merge_kernel (argmax_rerank.hip)
-// merges the groups.  Scores of listed windows are NaN (pre-pass) and never enter: the fix-up pass hands their exact
-// values to the merge (patch list).  Scores past the start of the fully clamped run (ext.h:152-154 makes them copies
-// of its first element) do not take part either; where the run's window is listed its first element is NaN like any
-// listed score and the merge takes the exact run value instead.
-constexpr int kRank = 1, kNoStore = 2;         // MODE bits of the tile-256 kernel
-constexpr int kTRankBufs = 3;
-constexpr int kTRankFloats = kTRankBufs * kTRows * 2 * 256;   // [chunk % 3][row][top | second][column-in-quad][lane]
-
-
-__device__ inline float rank_key(float v, int tag) {          // tag = 15 - disparity within the group
-  return __int_as_float((__float_as_int(v) & ~15) | tag);
-}
-__device__ inline float vmaxf_raw(float a, float b) {         // v_max_f32 without the canonicalising self-maxima
-  float r;                                                    // clang adds around llvm.maxnum; a NaN operand loses
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// min(a, b) that is -inf when either is NaN: v_med3_f32 returns min3 of its operands when one of them is a NaN.
-// (__builtin_amdgcn_fmed3f with a constant -inf is folded by clang into canonicalise + v_min: 3 instructions, and the
-// wrong NaN rule.)
-__device__ inline float vmin_nan_low(float a, float b) {
-  float r;
-  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(-INFINITY));
-  return r;
-}
-
 // KS = sub-quad shift of the wavefront's pattern-side operands, (12 - 2 * wave) % 4: 0 for even consumer wavefronts, 2
-// for odd ones.  Everything else that depends on the wavefront index (quad offset, halo slot, key tags, read-out
-// duty) is a run-time scalar, so the kernel carries TWO copies of the consumer loop, not seven: with one copy per
-// wavefront the seven hot loops of a workgroup (plus the loader's) are a 77 KB instruction working set (166 KB with
-// ranking) against a 64 KB instruction cache shared by two CUs.
-template <bool ACCUM, int MODE, int KS>
-__device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, float* __restrict__ rk0, float rank_eps,
-                                             int WAVE, int f, int dg, int lane, int w_lo, int h_lo, int h_hi,
-                                             int r_begin, int n_iters, int H, int W, int D) {
+// for odd ones.  Everything else that depends on the wavefront index (quad offset, halo slot) is a run-time scalar, so
+// the kernel carries TWO copies of the consumer loop, not seven: with one copy per wavefront the seven hot loops of a
+// workgroup (plus the loader's) are a 77 KB instruction working set against a 64 KB instruction cache shared by two CUs.
+template <bool ACCUM, int KS>
+__device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out, int WAVE, int f, int dg, int lane,
+                                             int w_lo, int h_lo, int h_hi, int r_begin, int n_iters, int H, int W, int D) {
   constexpr int TAIL = 4, STEP = lcm_ce(6, kTRows);               // block size 9
-  constexpr bool RANK = (MODE & kRank) != 0, STORE = (MODE & kNoStore) == 0;
   const long HW = (long)H * W;
   const int d_base = dg * kTDG + WAVE * kTND;
   // per-lane column arithmetic is kept to ONE register, 4 * lane: everything else about the column tile (w_lo) goes
@@ -1269,72 +1232,12 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
   const int kQ = (kOff0 - 1) / 4;                                  // disparity j = 1 sits one span slot below j = 0:
   constexpr int kS = KS;                                           // both come out of the same two aligned quads
   static_assert(kTND == 2 && (kTDG - 2) % 4 == 0, "two disparities per lane; (kOff0 - 1) % 4 alternates 0, 2");
-  const int tag0 = 15 - WAVE * kTND;                               // key tag of disparity j = 0 (j = 1: one less)
   // halo sums: lane 0 takes the left quad's suffix sums, lane 63 the right quad's prefix sums, others zero
   const int halo4 = lane == 63 ? 4 : 0;
   // applied as a multiplicative mask: hipcc 7.2 miscompiles the select form `halo_lane ? hq[i] : 0.f` here
   // (it zeroes the value for every lane < 63, lane 0 included)
   const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;
   auto quad = [](const float* p) { return *(const f32x4*)p; };
-
-  float* rank_lds = lds - kTRankFloats;                            // in front of the staging ring (see the kernel)
-  // consumer wavefronts that have disparities below D in this group share the read-out of the rank slots
-  const int n_active = min(kTWaves, (D - dg * kTDG + kTND - 1) / kTND);
-  // only the first column tile can reach the fully clamped run (d > w + TAIL needs d_base + 1 > w_lo + TAIL)
-  const bool run_masks = RANK && (d_base + kTND - 1 > w_lo + TAIL);
-  if constexpr (RANK) {
-    if (WAVE == 0) {
-      const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-      for (int k = 0; k < kTRankFloats / 256; ++k) *(f32x4*)(rank_lds + 256 * k + 4 * lane) = ninf;
-    }
-  }
-  // slot pair (top t, second q) of the lane's four columns -> the partial word of output row hh.  The tie flag uses
-  // the margin of |top| <= 2 (scores are correlations), a constant: strict >, so that a group the run mask emptied
-  // (top = second = -inf) gets no flag -- the word would turn into a NaN.
-  const float flag_margin = rank_eps >= 0.f ? rank_margin(rank_eps, 2.f) : -INFINITY;
-  auto rank_emit = [&](f32x4 t, f32x4 q, int hh) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int close = q[i] > t[i] - flag_margin ? 16 : 0;
-      t[i] = __int_as_float((__float_as_int(t[i]) & ~16) | close);
-    }
-    // opaque uniform offset + unsigned 32-bit lane offset: the store takes an SGPR base, no per-lane pointer to keep
-    long roff = (long)hh * W + w_lo;                                // (an opaque POINTER would turn the store into a flat one)
-    asm("" : "+s"(roff));
-    if (lane_out) __builtin_nontemporal_store(t, (f32x4*)(rk0 + roff + l4));
-  };
-  // rows of chunk `ch` whose read-out falls to this wavefront: slots -> partial plane, reset
-  auto rank_readout = [&](int ch) {
-    float* sb = rank_lds + (ch % kTRankBufs) * (kTRows * 2 * 256) + lane;
-#pragma unroll
-    for (int s = 0; s < kTRows; ++s) {
-      const int hh = r_begin + ch * kTRows + s - TAIL;
-      if (hh >= h_lo && hh < h_hi && (s + ch) % n_active == WAVE) {      // wave-uniform
-        float* sl = sb + s * 2 * 256;
-        f32x4 t, q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { t[i] = sl[64 * i]; q[i] = sl[256 + 64 * i]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { sl[64 * i] = -INFINITY; sl[256 + 64 * i] = -INFINITY; }
-        rank_emit(t, q, hh);
-      }
-    }
-  };
-  // The runner-up update needs the value the first atomic returns: it is issued at the start of the next row, behind
-  // that row's operand reads -- LDS answers in order, so the returns are there by the time the operands are --
-  // instead of being waited for on its own.  Unconditional (a row without outputs leaves -inf here, a no-op for the
-  // maximum): a flag would keep these twelve registers alive across the whole loop.
-  float rk_hi[4], rk_lo[4], rk_old[4];
-  float* rk_sl = rank_lds + lane;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
-  auto rank_second = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      (void)__hip_atomic_fetch_max(rk_sl + 256 + 64 * i, __builtin_amdgcn_fmed3f(rk_old[i], rk_hi[i], rk_lo[i]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
 
   wg_barrier();                                                    // chunk 0 (operands + halos) is in LDS
   if (d_base >= D) {
@@ -1349,31 +1252,11 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
     for (int u = 0; u < STEP; ++u) {
       const int r = r_begin + it * STEP + u;
       const bool last_of_chunk = (u % kTRows) == kTRows - 1;
-      // Read-out of the chunk before last, one of its rows per row of this chunk, by the wavefront whose turn it is:
-      // the slot reads are requested here, ahead of the row's operands, and turned into the partial word only after
-      // phase A -- the read-out wave is the straggler of its chunk barrier, so its LDS round trip must not be exposed.
-      bool ro = false;
-      int ro_h = 0;
-      float* ro_sl = rank_lds;
-      f32x4 ro_t, ro_q;
-      asm("" : "=v"(ro_t), "=v"(ro_q));                            // defined (no code) on the path that reads nothing
-      if constexpr (RANK) {
-        const int rch = chunk - 2, rs = u % kTRows;
-        ro_h = r_begin + rch * kTRows + rs - TAIL;
-        ro = rch >= 0 && ro_h >= h_lo && ro_h < h_hi && (rs + rch) % n_active == WAVE;      // wave-uniform
-        if (ro) {
-          ro_sl = rank_lds + ((rch % kTRankBufs) * kTRows + rs) * (2 * 256) + lane;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { ro_t[i] = ro_sl[64 * i]; ro_q[i] = ro_sl[256 + 64 * i]; }
-        }
-      }
       // Phase A, every row: products and the vertical 3+3+3 rings of both disparities (needs only the two value
       // quads).  Phase B, output rows only (wave-uniform branch; the (bs-1) warm-up rows of a band skip it):
       // statistics quads requested first so that they arrive under the horizontal sums, then window sums,
       // normalisation and the store.
-      // One per-lane base per row, made opaque: every LDS operand of the row is then base + 16-bit immediate.  (Left
-      // alone the compiler hoists one base VGPR per ring row whose offset does not fit the immediate -- with the
-      // rank slots in front of the ring that is 3 spilled registers, reloaded behind a vmcnt(0) wait every row.)
+      // One per-lane base per row, made opaque: every LDS operand of the row is then base + 16-bit immediate.
       // (Likewise every address below is an opaque per-row SCALAR plus one of two loop-invariant lane registers, l4 or
       // halo4: anything the compiler can prove loop-invariant it hoists into a register of its own, and there are none
       // to spare.)
@@ -1392,9 +1275,8 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
       int hq_o = hq_s + halo4;
       asm("" : "+v"(hq_o));
       const float* hqp = lds + hq_o;                               // halo sums of (this wave, j 0) on this lane's side
-      // The value quads of a chunk's first row are read here; those of its other rows were requested at the end of
-      // the previous row, AHEAD of that row's returning atomics: LDS answers in order, and a read queued behind the
-      // atomics would make phase A wait for their round trip.
+      // The value quads of a chunk's first row are read here; those of its other rows were requested under phase B of
+      // the previous row.
       if ((u % kTRows) == 0) {
         qa = quad(own);
         qb0 = quad(pat);
@@ -1416,15 +1298,6 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
           x[j][i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
           T[j][i][u % 6] = t3;
         }
-      // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
-      if constexpr (RANK) {
-        rank_second();
-        if (ro) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { ro_sl[64 * i] = -INFINITY; ro_sl[256 + 64 * i] = -INFINITY; }
-          rank_emit(ro_t, ro_q, ro_h);
-        }
-      }
       auto prefetch_next = [&]() {                                 // next row of the same chunk: one ring row further
         if (!last_of_chunk) {
           qa = quad(own + kTPack);
@@ -1436,11 +1309,8 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
         f32x4 qma = quad(own + kTA), qsa = quad(own + 2 * kTA);
         f32x4 qm0 = quad(pat + kTSpanPad), qm1 = quad(pat + kTSpanPad + 4);
         f32x4 qs0 = quad(pat + 2 * kTSpanPad), qs1 = quad(pat + 2 * kTSpanPad + 4);
-        // without ranking the next row's value quads are requested here, under the whole of phase B; with it there
-        // are no 12 registers to spare until the normalisation is done (see below)
-        if constexpr (!RANK) prefetch_next();
+        prefetch_next();                                           // requested under the whole of phase B
         float me[8], se[8];
-        float key[kTND][4];
 #pragma unroll
         for (int j = 0; j < kTND; ++j) {
           float pre[4], suf[4];
@@ -1471,7 +1341,7 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             val[i] = cov * ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
           }
           const int d = d_base + j;
-          if (STORE && lane_out && d < D) {
+          if (lane_out && d < D) {
             long ooff = (long)d * HW + (long)h * W;
             asm("" : "+s"(ooff));
             float4* o = (float4*)(vol + ooff + l4);
@@ -1483,77 +1353,27 @@ __device__ __forceinline__ void t256_consume(float* lds, float* __restrict__ out
             // written once, next read by another kernel after 1.8 GB more: non-temporal (-8 % on the launch)
             __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, (f32x4*)o);
           }
-          if constexpr (RANK) {
-            if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) key[j][i] = rank_key(val[i], tag0 - j);
-              if (run_masks) {                                     // wave-uniform: first column tile only
-                // d > w + TAIL: copy of the run's first element (which itself is NaN, i.e. left to the merge, when
-                // the run's window is listed).  Loop-invariant compare: hoisted into a lane mask.
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  if (d - TAIL - i - w_lo > (int)l4) key[j][i] = -INFINITY;
-              }
-            } else {
-              // (volatile: as plain assignments the compiler runs these four moves on EVERY row, ahead of the branch)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0xff800000" : "=v"(key[j][i]));
-            }
-          }
-        }
-        if constexpr (RANK) prefetch_next();
-        if constexpr (RANK) {
-          rk_sl = rank_lds + (((chunk % kTRankBufs) * kTRows + (u % kTRows)) * 2) * 256 + lane;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            // NaN keys (scores of listed windows) drop out: v_max returns the other operand, med3 with a NaN its min3
-            rk_hi[i] = vmaxf_raw(key[0][i], key[1][i]);
-            rk_lo[i] = vmin_nan_low(key[0][i], key[1][i]);
-            rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
         }
       } else {
         prefetch_next();
-        if constexpr (RANK) {
-          // only the returned old top is reset: the next rank_second() then offers min(hi, lo) of the last output row
-          // once more -- a genuine non-top key of that pixel, harmless -- instead of twelve moves that the compiler
-          // runs on EVERY row, ahead of the branch (resetting all three), or ten spilled registers (resetting none)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) rk_old[i] = -INFINITY;
-        }
       }
       if (last_of_chunk) {
-        if constexpr (RANK) {
-          // the band's last chunk has no next row to ride on: complete its slots before its barrier (wave-uniform)
-          if (it == n_iters - 1 && u == STEP - 1) {
-            rank_second();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = -INFINITY;
-          }
-        }
         wait_lgkmcnt0();
         wg_barrier();
         ++chunk;
       }
     }
   }
-  if constexpr (RANK) {
-    rank_readout(chunk - 2);                                       // n_chunks is even and >= 2
-    rank_readout(chunk - 1);
-  }
 }
 
-template <bool ACCUM, int MODE>
+template <bool ACCUM>
 __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
-    float* __restrict__ out, float* __restrict__ rank0, float rank_eps, int C, int c, int H, int W, int D,
-    int band_rows, int n_dgroups, int Wp, int W1, int xoff) {
+    float* __restrict__ out, int C, int c, int H, int W, int D, int band_rows, int n_dgroups, int Wp, int W1, int xoff) {
   constexpr int HALF = 4, TAIL = 4, STEP = lcm_ce(6, kTRows), CPI = STEP / kTRows;   // chunks per outer iteration
-  // ranking: [kTRankFloats] rank slots first (their addresses then fit the 16-bit DS offset), then the staging ring
-  extern __shared__ float lds_all[];
-  float* lds = lds_all + ((MODE & kRank) ? kTRankFloats : 0);   // [kTBufs][kTRows][kTPack]
-  // the wave index feeds scalar arithmetic (disparity base, LDS offsets, key tags): make it a scalar for the compiler
+  extern __shared__ float lds[];                                  // [kTBufs][kTRows][kTPack]
+  // the wave index feeds scalar arithmetic (disparity base, LDS offsets): make it a scalar for the compiler
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int f = blockIdx.z / n_dgroups, dg = blockIdx.z - f * n_dgroups;
   const int w_lo = blockIdx.x * kTTile;
@@ -1623,8 +1443,6 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
       const float* buf = lds + (chunk % kTBufs) * (kTRows * kTPack);
 #pragma unroll
       for (int s = 0; s < kTRows; ++s) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int u = (UB + s) % 6;
         const float* pk = buf + s * kTPack;
         float x[4];
@@ -1683,13 +1501,470 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
     return;
   }
 
-  // partial plane of this (frame, disparity group)
-  float* rk0 = (MODE & kRank) ? rank0 + (long)blockIdx.z * H * W : nullptr;
   // two copies of the consumer loop: the sub-quad shift of the pattern-side operands alternates with the wave index
   if (wave & 1)
-    t256_consume<ACCUM, MODE, (kTDG - 2 - kTND) % 4>(lds, out, rk0, rank_eps, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
+    t256_consume<ACCUM, (kTDG - 2 - kTND) % 4>(lds, out, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
   else
-    t256_consume<ACCUM, MODE, (kTDG - 2) % 4>(lds, out, rk0, rank_eps, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
+    t256_consume<ACCUM, (kTDG - 2) % 4>(lds, out, wave, f, dg, lane, w_lo, h_lo, h_hi, r_begin, n_iters, H, W, D);
+}
+
+// ------------------------------------------------------------------------------------
+// ALL-D kernel (bs == 9, W % 4 == 0, C == 1): volume + in-kernel ranking, what ctd_xcorrvol_argmax_f32 launches.
+//
+// Same consumer pipeline as the tile-256 kernel, but ONE workgroup owns a (256-column tile, band of rows, frame) for
+// EVERY disparity: 15 consumer wavefronts + 1 loader (1024 threads, one workgroup per CU = four wavefronts on every
+// SIMD), 2 disparities per lane, so a pass over the band covers up to 30 disparities and the workgroup makes
+// ceil(D / 30) passes (the disparities are dealt evenly: D = 128 -> 5 passes of 26 on 13 wavefronts).  What that buys:
+//   * the ranking state lives in LDS for the whole band -- two u32 slots {top, runner-up} per pixel, fed by LDS
+//     atomics from all consumer wavefronts across all passes -- and what leaves the kernel is the final index (int64),
+//     the best score, the work-list flag: no per-group partial planes (141 MB at config 2) and no merge kernel;
+//   * the frame-side operands of the band are re-read by the SAME workgroup on every pass (the same CU, the same L2)
+//     instead of by ten workgroups scattered over the eight XCDs' L2s;
+//   * half the passes for the loader's DMA and halo work, 15 of 16 wavefronts computing instead of 7 of 8;
+//   * at most 256 workgroups are resident: the store-only ceiling of exactly this pattern is 6.0-6.7 TB/s against
+//     5.8-6.0 for the per-group grid (profiles/round3_store_ceiling.txt).
+// KEY of a score: t = 6 + score lies in [4, 8) for every |score| <= 1 + 1e-5, where consecutive floats are 2^-21 apart
+// and ordered like their bit patterns: key = (bits(t) << 9) | (511 - d) is an unsigned integer ordered by score first
+// (absolute resolution 2^-21 = 4.8e-7, against 2^-19 RELATIVE for the mantissa-tag keys it replaces) and by LOWER
+// disparity second -- so u32 maxima carry the argmax with first-index-wins ties.  Per pixel:
+//     old = ds_max_rtn_u32(top, hi);  ds_max_u32(second, med3(old, hi, lo))      (hi >= lo: the lane's two keys)
+// -- every key that is not the final maximum is, at some point, the loser of such an exchange, so `second` ends up as
+// the runner-up; the second atomic rides on the next row (its operand is the first one's return value).
+// Scores of LISTED windows: the pre-pass stores a zero reciprocal deviation for them, so the kernels produce the
+// placeholder score 0 for exactly the outputs the fix-up pass recomputes.  A placeholder can only matter for the
+// ranking if it comes out on top or within the margin of the top: ncc_fixup_kernel sends a pixel to the exact
+// re-scoring when the exact score is a contender OR when the pixel's index is the placeholder's disparity.  Scores past
+// the start of the fully clamped run (ext.h:152-154 makes them copies of its first element) get key 0.
+// ------------------------------------------------------------------------------------
+constexpr int kAWaves = 15;                    // consumer wavefronts per workgroup
+constexpr int kADGMax = kAWaves * 2;           // disparities per pass, at most
+constexpr int kAA = 256 + 8;                   // frame-side array: 4 halo columns either side
+constexpr int kASpanPad = (kAA + kADGMax - 1 + 1 + 3) / 4 * 4;   // 296: multiple of 4, > span
+static_assert(kAA + kADGMax - 1 < kASpanPad, "pattern span must fit its padded array");
+constexpr int kAHalo = kAWaves * 2 * 2 * 4;    // [wave][j][side][4] halo sums
+constexpr int kAPack = 3 * kAA + 3 * kASpanPad + kAHalo;   // 1920 floats per staged row
+constexpr int kARows = 3, kABufs = 3;
+constexpr int kADmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
+constexpr int kAOffB = 3 * kAA, kAOffH = 3 * kAA + 3 * kASpanPad;
+constexpr int kAMaxBandRows = 44;              // rank slots (2 KB per row) + staging ring <= 160 KB
+constexpr int kTagBits = 9;                    // D <= 512
+constexpr unsigned kTagMask = (1u << kTagBits) - 1u;
+constexpr float kKeyBias = 6.f;
+static_assert((size_t)kAMaxBandRows * 2048 + sizeof(float) * kABufs * kARows * kAPack <= 160 * 1024, "LDS budget");
+
+__device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// fixed-point units of the keys per unit of score, and the re-ranking margin in those units (ctd_rank.h: rank_margin)
+__device__ inline unsigned key_margin_units(float eps) { return (unsigned)ceilf(rank_margin(eps, 1.f) * 2097152.f); }
+
+template <bool STORE, int KS>
+__device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, float* __restrict__ out, int WAVE, int f,
+                                             int lane, int w_lo, int h_lo, int h_hi, int r_begin, int n_iters,
+                                             int n_pass, int dgs, int H, int W, int D) {
+  constexpr int TAIL = 4, STEP = 6, CPI = STEP / kARows;          // block size 9
+  static_assert(STEP % kARows == 0, "a chunk never straddles two outer iterations");
+  const long HW = (long)H * W;
+  const unsigned l4 = 4u * (unsigned)lane;                         // first column of the lane, relative to w_lo
+  float* vol = out + (long)f * D * HW + w_lo;
+  const bool lane_out = w_lo + (int)l4 < W;
+  float P[2][4][2], T[2][4][6];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      P[j][i][0] = P[j][i][1] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) T[j][i][k] = 0.f;
+    }
+  const int kOff0 = (dgs - 1) - WAVE * 2;                          // span slot offset of disparity j = 0
+  const int kQ = (kOff0 - 1) / 4;                                  // disparity j = 1 sits one span slot below j = 0:
+  constexpr int kS = KS;                                           // both come out of the same two aligned quads
+  const int halo4 = lane == 63 ? 4 : 0;
+  const float halo_mask = (lane == 0 || lane == 63) ? 1.f : 0.f;  // (multiplicative: see t256_consume)
+  auto quad = [](const float* p) { return *(const f32x4*)p; };
+
+  // The runner-up update needs the value the first atomic returns: it is issued at the start of the next row, behind
+  // that row's operand reads -- LDS answers in order, so the returns are there by the time the operands are.
+  // Unconditional (a row without outputs leaves key 0 here, a no-op for the maximum): a flag would keep these twelve
+  // registers alive across the whole loop.
+  unsigned rk_hi[4], rk_lo[4], rk_old[4];
+  unsigned* rk_sl = rank_lds + lane;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = 0u;
+  auto rank_second = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      (void)__hip_atomic_fetch_max(rk_sl + 256 + 64 * i, umed3(rk_old[i], rk_hi[i], rk_lo[i]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  wg_barrier();                                                    // chunk 0 (operands + halos) and the cleared slots are in LDS
+  int slot = 0;                                                    // ring slot of the current chunk
+  f32x4 qa, qb0, qb1;                                              // value quads of the row (frame, pattern x 2)
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int d_base = pass * dgs + WAVE * 2;
+    if (WAVE * 2 >= dgs || d_base >= D) {
+      // a wavefront without disparities in this pass (the pass is narrower than 15 pairs, or it is the last pass and
+      // both disparities lie past D): keep the barrier protocol, skip the work
+      for (int k = 0; k < n_iters * CPI; ++k) {
+        wg_barrier();
+        slot = slot == kABufs - 1 ? 0 : slot + 1;
+      }
+      continue;
+    }
+    const unsigned tag0 = kTagMask - (unsigned)d_base;             // key tag of disparity j = 0 (j = 1: one less)
+    // only the first column tile can reach the fully clamped run (d > w + TAIL needs d_base + 1 > w_lo + TAIL)
+    const bool run_masks = d_base + 1 > w_lo + TAIL;
+    for (int it = 0; it < n_iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < STEP; ++u) {
+        const int r = r_begin + it * STEP + u;
+        const bool last_of_chunk = (u % kARows) == kARows - 1;
+        // (addressing: one opaque per-row scalar plus one of two loop-invariant lane registers, see t256_consume)
+        int row_o = (slot * kARows + (u % kARows)) * kAPack + 4;
+        asm("" : "+s"(row_o));
+        int own_o = row_o + (int)l4;
+        asm("" : "+v"(own_o));
+        const float* own = lds + own_o;                            // own quad after the left halo
+        int pat_s = row_o + kAOffB + 4 * kQ;
+        asm("" : "+s"(pat_s));
+        int pat_o = pat_s + (int)l4;
+        asm("" : "+v"(pat_o));
+        const float* pat = lds + pat_o;                            // first of the lane's two pattern-side quads
+        int hq_s = row_o - 4 + kAOffH + WAVE * (2 * 2 * 4);
+        asm("" : "+s"(hq_s));
+        int hq_o = hq_s + halo4;
+        asm("" : "+v"(hq_o));
+        const float* hqp = lds + hq_o;                             // halo sums of (this wave, j 0) on this lane's side
+        // The value quads of a chunk's first row are read here; those of its other rows were requested at the end of
+        // the previous row, AHEAD of that row's returning atomics: LDS answers in order, and a read queued behind the
+        // atomics would make phase A wait for their round trip.
+        if ((u % kARows) == 0) {
+          qa = quad(own);
+          qb0 = quad(pat);
+          qb1 = quad(pat + 4);
+        }
+        asm("" : "+v"(qa), "+v"(qb0), "+v"(qb1));
+        const float av[4] = {qa[0], qa[1], qa[2], qa[3]};
+        const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
+        const int h = r - TAIL;
+        const bool row_out = (h >= h_lo) && (h < h_hi);           // wave-uniform
+        float x[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float p = av[i] * be[kS + (1 - j) + i];          // b[j][i] = slot kOff0 - j + i
+            const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
+            P[j][i][u % 2] = p;
+            x[j][i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+            T[j][i][u % 6] = t3;
+          }
+        // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
+        rank_second();
+        auto prefetch_next = [&]() {                               // next row of the same chunk: one ring row further
+          if (!last_of_chunk) {
+            qa = quad(own + kAPack);
+            qb0 = quad(pat + kAPack);
+            qb1 = quad(pat + kAPack + 4);
+          }
+        };
+        if (row_out) {
+          f32x4 qma = quad(own + kAA), qsa = quad(own + 2 * kAA);
+          f32x4 qm0 = quad(pat + kASpanPad), qm1 = quad(pat + kASpanPad + 4);
+          f32x4 qs0 = quad(pat + 2 * kASpanPad), qs1 = quad(pat + 2 * kASpanPad + 4);
+          float me[8], se[8];
+          unsigned key[2][4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float pre[4], suf[4];
+            pre[0] = x[j][0];
+            pre[1] = pre[0] + x[j][1];
+            pre[2] = pre[1] + x[j][2];
+            pre[3] = pre[2] + x[j][3];
+            suf[3] = x[j][3];
+            suf[2] = suf[3] + x[j][2];
+            suf[1] = suf[2] + x[j][1];
+            suf[0] = suf[1] + x[j][0];
+            float sj[4];
+            window_combine4(suf, pre[3], pre, sj);                  // wave-edge lanes get 0 from the missing neighbour
+            if (j == 0) {
+              // statistics quads: pinned after the first window sums (data dependency keeps the wait here)
+              asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
+              asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
+            }
+            f32x4 hq = quad(hqp + j * 2 * 4);
+            asm("" : "+v"(hq));
+            const int d = d_base + j;
+            float val[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float sh = fmaf(halo_mask, hq[i], sj[i]);
+              const float cov = fmaf(qma[i], me[kS + (1 - j) + i], sh);   // qma = -bs^2 * (window mean), from the pre-pass
+              const float inv = ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
+              if (STORE) val[i] = cov * inv;                        // the same bits as the plain volume kernels'
+              key[j][i] = (__float_as_uint(fmaf(cov, inv, kKeyBias)) << kTagBits) | (tag0 - (unsigned)j);
+            }
+            if (STORE && lane_out && d < D) {
+              long ooff = (long)d * HW + (long)h * W;
+              asm("" : "+s"(ooff));
+              // written once, next read by another kernel after 1.8 GB more: non-temporal
+              __builtin_nontemporal_store(f32x4{val[0], val[1], val[2], val[3]}, (f32x4*)(vol + ooff + l4));
+            }
+            if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
+              if (run_masks) {                                     // wave-uniform: first column tile only
+                // d > w + TAIL: copy of the run's first element.  Loop-invariant compare: hoisted into a lane mask.
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (d - TAIL - i - w_lo > (int)l4) key[j][i] = 0u;
+              }
+            } else {
+              // (volatile: as plain assignments the compiler runs these four moves on EVERY row, ahead of the branch)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(key[j][i]));
+            }
+          }
+          prefetch_next();
+          // slots of output row h: [row][top | second][column-in-quad][lane]
+          rk_sl = rank_lds + (it * STEP + u - 2 * TAIL) * 512 + lane;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            rk_hi[i] = max(key[0][i], key[1][i]);
+            rk_lo[i] = min(key[0][i], key[1][i]);
+            rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        } else {
+          prefetch_next();
+          // only the returned old top is reset: the next rank_second() then offers min(hi, lo) of the last output row
+          // once more -- a genuine non-top key of that pixel, harmless
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rk_old[i] = 0u;
+        }
+        if (last_of_chunk) {
+          // the pass's last chunk has no next row to ride on: complete its slots before its barrier (wave-uniform)
+          if (it == n_iters - 1 && u == STEP - 1) {
+            rank_second();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = 0u;
+          }
+          wait_lgkmcnt0();
+          wg_barrier();
+          slot = slot == kABufs - 1 ? 0 : slot + 1;
+        }
+      }
+    }
+  }
+}
+
+// MODE_STORE: the volume is materialised as well; otherwise nothing but indices / best scores / work list leave.
+template <bool STORE>
+__global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
+    const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
+    const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
+    float* __restrict__ out, int64_t* __restrict__ idx_out, float* __restrict__ best_out,
+    unsigned char* __restrict__ flags_out, WorkList work, float rank_eps, int H, int W, int D, int band_rows, int n_pass,
+    int dgs, int Wp, int W1, int xoff) {
+  constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / kARows;
+  // [band_rows][top | second][256] rank slots first (their row base goes into one lane register), then the staging ring
+  extern __shared__ float lds_all[];
+  unsigned* rank_lds = (unsigned*)lds_all;
+  float* lds = lds_all + band_rows * 512;                          // [kABufs][kARows][kAPack]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int f = blockIdx.z;
+  const int w_lo = blockIdx.x * 256;
+  const int h_lo = blockIdx.y * band_rows;
+  const int h_hi = min(h_lo + band_rows, H);
+  const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
+  const int n_rows = r_end - r_begin + 1;
+  const int n_iters = (n_rows + STEP - 1) / STEP;
+  const int n_chunks = n_iters * CPI;                              // per pass; even
+  const int n_act = dgs / 2;                                       // consumer wavefronts with work
+
+  // every wavefront clears its share of the rank slots (key 0 = below every score)
+  for (int k = threadIdx.x; k < band_rows * 128; k += 64 * (kAWaves + 1)) ((uint4*)rank_lds)[k] = make_uint4(0u, 0u, 0u, 0u);
+  wait_lgkmcnt0();                                                 // (the consumers' first barrier is a raw s_barrier)
+
+  if (wave == kAWaves) {
+    // every chunk barrier waits for this wavefront's DMA issue and halo sums: it goes first on its SIMD
+    __builtin_amdgcn_s_setprio(3);
+    // ------------------------------ loader + halo wavefront ------------------------------
+    const float* a_img = ac + (long)f * H * Wp + 4;               // +4: column c lives at c + 4
+    const float* m0i = m0 + (long)f * H * Wp + 4;
+    const float* v0i = v0 + (long)f * H * Wp + 4;
+    const float* b_img = bc + (long)f * st1_frame_stride;
+    const float* m1i = m1 + (long)f * st1_frame_stride;
+    const float* v1i = v1 + (long)f * st1_frame_stride;
+    const int c_lo = w_lo - 4;
+    const int aq0 = min(c_lo + 4 * lane, Wp - 8), aq1 = min(c_lo + 256 + 4 * lane, Wp - 8);
+    const bool a_tail = 256 + 4 * lane < kAA, s_tail = 256 + 4 * lane < kASpanPad;
+    const int total = n_pass * n_chunks;                           // chunks of the whole workgroup, all passes
+    int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;                 // the next chunk to issue: ring slot, pass, chunk in the pass
+    auto issue_chunk = [&]() {
+      float* buf = lds + i_slot * (kARows * kAPack);
+      const int xb = c_lo - (i_pass * dgs + dgs - 1);              // unclamped pattern column of span slot 0
+      const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
+#pragma unroll
+      for (int s = 0; s < kARows; ++s) {
+        const int r = r_begin + i_ch * kARows + s;
+        const int rc = clampi(r, 0, H - 1);
+        const int hs = clampi(r - TAIL, 0, H - 1);
+        float* pk = buf + s * kAPack;
+        dma_quad(a_img + (long)rc * Wp + aq0, pk);
+        dma_quad(m0i + (long)hs * Wp + aq0, pk + kAA);
+        dma_quad(v0i + (long)hs * Wp + aq0, pk + 2 * kAA);
+        dma_quad(b_img + (long)rc * W1 + sq0, pk + kAOffB);
+        dma_quad(m1i + (long)hs * W1 + sq0, pk + kAOffB + kASpanPad);
+        dma_quad(v1i + (long)hs * W1 + sq0, pk + kAOffB + 2 * kASpanPad);
+        if (a_tail) {
+          dma_quad(a_img + (long)rc * Wp + aq1, pk + 256);
+          dma_quad(m0i + (long)hs * Wp + aq1, pk + kAA + 256);
+          dma_quad(v0i + (long)hs * Wp + aq1, pk + 2 * kAA + 256);
+        }
+        if (s_tail) {
+          dma_quad(b_img + (long)rc * W1 + sq1, pk + kAOffB + 256);
+          dma_quad(m1i + (long)hs * W1 + sq1, pk + kAOffB + kASpanPad + 256);
+          dma_quad(v1i + (long)hs * W1 + sq1, pk + kAOffB + 2 * kASpanPad + 256);
+        }
+      }
+      ++i_n;
+      i_slot = i_slot == kABufs - 1 ? 0 : i_slot + 1;
+      if (++i_ch == n_chunks) { i_ch = 0; ++i_pass; }
+    };
+    // halo job of this lane: consumer wave cw, disparity j, side (0 = quad left of the tile, 1 = right of it)
+    const int cw = lane >> 2, hj = (lane >> 1) & 1, side = lane & 1;
+    const bool has_job = cw < n_act;
+    const int a_slot = side ? (kAA - 4) : 0;
+    const int b_slot = has_job ? a_slot + (dgs - 1) - (cw * 2 + hj) : 0;
+    float hP[4][2], hT[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hP[i][0] = hP[i][1] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) hT[i][k] = 0.f;
+    }
+    // vertical ring update of the halo quad for the rows of one chunk; UB = ring phase of its first row.  (The rings
+    // run on across passes: the first 8 rows of a pass are warm-up rows, whatever the rings held before.)
+    int h_slot = 0;                                                // ring slot of the next chunk to get its halo sums
+    auto halo_chunk = [&](auto ub_tag) {
+      constexpr int UB = decltype(ub_tag)::value;
+      const float* buf = lds + h_slot * (kARows * kAPack);
+#pragma unroll
+      for (int s = 0; s < kARows; ++s) {
+        const int u = (UB + s) % 6;
+        const float* pk = buf + s * kAPack;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = has_job ? pk[a_slot + i] * pk[kAOffB + b_slot + i] : 0.f;
+          const float t3 = p + hP[i][(u + 1) % 2] + hP[i][u % 2];
+          hP[i][u % 2] = p;
+          x[i] = t3 + hT[i][(u + 3) % 6] + hT[i][u % 6];
+          hT[i][u % 6] = t3;
+        }
+        float o4[4];
+        if (side) {                                                // prefix sums: columns 0..i of the right quad
+          o4[0] = x[0]; o4[1] = o4[0] + x[1]; o4[2] = o4[1] + x[2]; o4[3] = o4[2] + x[3];
+        } else {                                                   // suffix sums: columns i..3 of the left quad
+          o4[3] = x[3]; o4[2] = o4[3] + x[2]; o4[1] = o4[2] + x[1]; o4[0] = o4[1] + x[0];
+        }
+        if (has_job) {
+          float* hq = const_cast<float*>(pk) + kAOffH + lane * 4;  // lane == ((cw*2 + hj)*2 + side)
+          hq[0] = o4[0]; hq[1] = o4[1]; hq[2] = o4[2]; hq[3] = o4[3];
+        }
+      }
+      h_slot = h_slot == kABufs - 1 ? 0 : h_slot + 1;
+    };
+    constexpr int L = kARows * kADmaPerRow;
+    static_assert(L * (kABufs - 2) < 64, "in-flight DMA count must fit vmcnt");
+    static_assert(kABufs == 3 && CPI == 2, "the loop below spells out two chunks per iteration and a ring of three");
+    issue_chunk();                                                 // total >= 2 (n_chunks is even)
+    issue_chunk();
+    wait_vmcnt<L>();                                               // chunk 0 has landed
+    halo_chunk(std::integral_constant<int, 0>{});
+    wait_lgkmcnt0();
+    wg_barrier();
+    // chunk g of the flat sequence is chunk g % n_chunks of pass g / n_chunks: since n_chunks is even, the ring phase
+    // of a chunk's first row is 0 for even g and 3 for odd g, across pass boundaries too
+    for (int g = 0; g < total; g += 2) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (i_n < total) {
+          issue_chunk();
+          wait_vmcnt<L>();                                         // chunk g + cc + 1 has landed
+        } else {
+          wait_vmcnt<0>();
+        }
+        if (g + cc + 1 < total) {
+          if (cc == 0) halo_chunk(std::integral_constant<int, 3>{});
+          else halo_chunk(std::integral_constant<int, 0>{});
+        }
+        wait_lgkmcnt0();
+        wg_barrier();
+      }
+    }
+    return;
+  }
+
+  // two copies of the consumer loop: the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * wave) % 4
+  if ((dgs - 2 - 2 * wave) & 2)
+    alld_consume<STORE, 2>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, dgs, H, W, D);
+  else
+    alld_consume<STORE, 0>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, dgs, H, W, D);
+
+  // ---- emit: the band's final {top, second} -> index, best score, work-list flag.  The last chunk barrier (behind
+  // every wavefront's lgkmcnt(0)) has made all slot updates visible.
+  const unsigned l4 = 4u * (unsigned)lane;
+  const bool lane_out = w_lo + (int)l4 < W;
+  const unsigned margin = rank_eps >= 0.f ? key_margin_units(rank_eps) : 0u;
+  for (int row = wave; row < h_hi - h_lo; row += kAWaves) {
+    const unsigned* sl = rank_lds + row * 512 + lane;
+    const long p0 = ((long)f * H + h_lo + row) * W + w_lo + l4;    // first of the lane's four pixels
+    long d64[4];
+    f32x4 b4;
+    unsigned listed4 = 0, n_hard = 0;
+    bool hard[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned t = sl[64 * i], q = sl[256 + 64 * i];
+      d64[i] = (long)(kTagMask - (t & kTagMask));
+      const unsigned ft = t >> kTagBits, fq = q >> kTagBits;       // 23-bit fixed-point scores
+      b4[i] = __uint_as_float(0x40800000u | ft) - kKeyBias;
+      // runner-up within the margin of the best -> exact re-scoring (q == 0: the pixel has a single score)
+      hard[i] = lane_out && rank_eps >= 0.f && q != 0u && ft - fq <= margin;
+      if (hard[i]) { listed4 |= 1u << (8 * i); ++n_hard; }
+    }
+    if (lane_out) {
+      typedef long l64x2 __attribute__((ext_vector_type(2)));
+      *(l64x2*)(idx_out + p0) = l64x2{d64[0], d64[1]};
+      *(l64x2*)(idx_out + p0 + 2) = l64x2{d64[2], d64[3]};
+      *(f32x4*)(best_out + p0) = b4;
+      *(unsigned*)(flags_out + p0) = listed4;
+    }
+    // all pixels of the row share the work-list key: one counter update per wavefront and row that has any
+    if (__any(n_hard != 0)) {
+      unsigned before = n_hard;                                    // exclusive prefix over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(before, o);
+        if (lane >= o) before += v;
+      }
+      const unsigned total_hard = __shfl(before, 63);
+      before -= n_hard;
+      const int key = worklist_key(work, p0);
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(work.counters + key * kWorkListStride, total_hard);
+      base = __shfl(base, 0);
+      int64_t* dst = work.list + (long)key * work.seg_cap + base + before;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (hard[i]) *dst++ = p0 + i;
+    }
+  }
 }
 
 struct FastWorkspace {
@@ -1706,7 +1981,9 @@ struct FastWorkspace {
 
 static FastWorkspace fast_workspace(void* base, int frames, int C, int H, int W, int D, bool per_frame_pattern) {
   FastWorkspace ws;
-  const int Dpad = (D + kFDG - 1) / kFDG * kFDG;
+  // + 32: the last disparity group (tile-256 kernel) / pass (all-D kernel) stages pattern columns for up to 29
+  // disparities past D; their outputs are never stored, their operands still come from inside the plane
+  const int Dpad = (D + kFDG - 1) / kFDG * kFDG + 32;
   // x = w - d ranges over [-(Dpad-1) - 4, W + 3] (4 halo columns either side).  xoff = 3 (mod 4) makes
   // the first span slot of every workgroup 16-byte aligned (w_lo and the disparity-group base are
   // multiples of 4), which the dwordx4 LDS-DMA of the wide kernel relies on.
@@ -1749,32 +2026,58 @@ bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs) {
 static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, int D) {
   RankPlan rp;
   rp.eps = 0.f;
-  rp.n_dg = ceil_div(D, kTDG);
-  rp.dg_size = kTDG;
-  const size_t npart = align_up((size_t)frames * rp.n_dg * H * W * sizeof(float), 256);
+  rp.idx = nullptr;
+  rp.best = nullptr;
+  (void)D;
   const size_t nflag = align_up((size_t)frames * H * W, 256);
   // work list: kWorkListParts segments keyed by image row, behind their counters (one cache line each)
   const long seg_cap = (long)ceil_div(frames * H, kWorkListParts) * W;
   const size_t ncnt = align_up(sizeof(unsigned) * kWorkListStride * kWorkListParts, 256);
   const size_t nlist = ncnt + align_up((size_t)kWorkListParts * seg_cap * sizeof(int64_t), 256);
   char* p = (char*)base + offset;
-  rp.k0 = (float*)p;
-  rp.flags = (unsigned char*)(p + npart);
-  rp.work.counters = (unsigned*)(p + npart + nflag);
-  rp.work.list = (int64_t*)(p + npart + nflag + ncnt);
+  rp.flags = (unsigned char*)p;
+  rp.work.counters = (unsigned*)(p + nflag);
+  rp.work.list = (int64_t*)(p + nflag + ncnt);
   rp.work.parts = kWorkListParts;
   rp.work.row_width = W;
   rp.work.seg_cap = seg_cap;
-  rp.best_scratch = (float*)(p + npart + nflag + nlist);
-  rp.bytes = offset + npart + nflag + nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
+  rp.best_scratch = (float*)(p + nflag + nlist);
+  rp.bytes = offset + nflag + nlist + align_up((size_t)frames * H * W * sizeof(float), 256);
   return rp;
+}
+
+// How the all-D kernel cuts a call into workgroups: disparities per pass (dealt evenly over ceil(D / 30) passes), and
+// the band height.  One workgroup per CU is resident (LDS), every workgroup costs about (rows + 8 warm-up rows) x passes,
+// so the bands are chosen to minimise ceil(workgroups / 256) x (band rows rounded up to the 6-row unroll + 8).
+struct AlldPlan {
+  int n_pass, dgs, band_rows, bands;
+  size_t lds;
+};
+static AlldPlan alld_plan(int frames, int H, int W, int D) {
+  AlldPlan ap;
+  ap.n_pass = ceil_div(D, kADGMax);
+  ap.dgs = 2 * ceil_div(ceil_div(D, 2), ap.n_pass);
+  const long base = (long)ceil_div(W, 256) * frames;
+  long best_cost = -1;
+  ap.band_rows = H < kAMaxBandRows ? H : kAMaxBandRows;
+  for (int rows = kAMaxBandRows; rows >= 4; --rows) {
+    if (rows > H) continue;
+    const long wgs = base * ceil_div(H, rows);
+    const long cost = ((wgs + 255) / 256) * (long)(ceil_div(rows + 8, 6) * 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; }
+  }
+  ap.bands = ceil_div(H, ap.band_rows);
+  ap.band_rows = ceil_div(H, ap.bands);                          // the same number of bands, evenly tall
+  ap.lds = (size_t)ap.band_rows * 2048 + sizeof(float) * kABufs * kARows * kAPack;
+  return ap;
 }
 
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off) {
   const FastWorkspace ws = fast_workspace(nullptr, frames, 1, H, W, D, per_frame_pattern);
   const RankPlan rp = rank_plan(nullptr, ws.bytes, frames, H, W, D);
-  off[0] = (size_t)rp.k0; off[1] = (size_t)rp.flags; off[2] = (size_t)rp.work.counters; off[3] = (size_t)rp.work.list;
-  off[4] = (size_t)rp.n_dg;
+  const AlldPlan ap = alld_plan(frames, H, W, D);
+  off[0] = (size_t)ap.band_rows; off[1] = (size_t)rp.flags; off[2] = (size_t)rp.work.counters; off[3] = (size_t)rp.work.list;
+  off[4] = (size_t)ap.n_pass;
 }
 
 size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern) {
@@ -1809,8 +2112,22 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
   constexpr int WOUT = 64 - (BS - 1);
   const long st1_stride = in1_frame_stride ? (long)C * H * ws.W1 : 0;
   if (rank && !(BS == 9 && W % 4 == 0 && C == 1 && ((uintptr_t)out) % 16 == 0)) return CTD_ERR_UNSUPPORTED;
+  if (rank) {
+    // ranked call: the all-D kernel (one workgroup per column tile, band and frame, every disparity)
+    const AlldPlan ap = alld_plan(frames, H, W, D);
+    dim3 grid(ceil_div(W, 256), ap.bands, frames), block(64 * (kAWaves + 1));
+    auto kern = out ? ncc_fast_alld_kernel<true> : ncc_fast_alld_kernel<false>;
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ap.lds));
+    timing_begin(stream);
+    hipLaunchKernelGGL(kern, grid, block, ap.lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
+                       rank->idx, rank->best, rank->flags, rank->work, rank->eps, H, W, D, ap.band_rows, ap.n_pass, ap.dgs,
+                       ws.Wp, ws.W1, ws.xoff);
+    timing_end(stream, W);
+    CTD_LAUNCH_CHECK();
+    return CTD_OK;
+  }
   if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0) {
-    // production path: 256-column tiles, every store a full aligned KB
+    // production path of the plain volume: 256-column tiles, every store a full aligned KB
     const int n_dg = ceil_div(D, kTDG);
     const int n_tiles = ceil_div(W, kTTile);
     // Bands of ~44 rows (5.5x the (bs-1)-row warm-up).  Measured on config 2 (H = 432): 4 bands 0.448 ms, 8: 0.418,
@@ -1819,16 +2136,14 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     const int bands = H >= 66 ? (H + 22) / 44 : 1;
     const int band_rows = ceil_div(H, bands);
     dim3 grid(n_tiles, ceil_div(H, band_rows), frames * n_dg), block(64 * (kTWaves + 1));
-    const size_t lds = sizeof(float) * (kTBufs * kTRows * kTPack + (rank ? kTRankFloats : 0));
+    const size_t lds = sizeof(float) * kTBufs * kTRows * kTPack;
     for (int c = 0; c < C; ++c) {
-      auto kern = c == 0 ? ncc_fast_t256_kernel<false, 0> : ncc_fast_t256_kernel<true, 0>;
-      if (rank) kern = out ? ncc_fast_t256_kernel<false, kRank> : ncc_fast_t256_kernel<false, kRank | kNoStore>;
+      auto kern = c == 0 ? ncc_fast_t256_kernel<false> : ncc_fast_t256_kernel<true>;
       if (lds > 64 * 1024)
         CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       timing_begin(stream);
-      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
-                         rank ? rank->k0 : nullptr, rank ? rank->eps : -1.f, C, c, H, W, D, band_rows, n_dg, ws.Wp,
-                         ws.W1, ws.xoff);
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out, C, c, H,
+                         W, D, band_rows, n_dg, ws.Wp, ws.W1, ws.xoff);
       timing_end(stream, W);
       CTD_LAUNCH_CHECK();
     }
@@ -1887,7 +2202,8 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
-                     ws.flag_a, ws.flag_b, ws.run_vals, rank && rank->eps >= 0.f ? best : nullptr, rank ? rank->eps : -1.f,
+                     ws.flag_a, ws.flag_b, ws.run_vals, rank ? best : nullptr, rank ? rank->idx : nullptr,
+                     rank ? rank->eps : -1.f,
                      rank ? (unsigned*)rank->flags : nullptr, rank ? rank->work : WorkList{}, frames, C, H, W, D, bs);
   CTD_LAUNCH_CHECK();
   if (!out) return CTD_OK;                                   // nothing to spread without a volume
@@ -1901,10 +2217,10 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
   return CTD_OK;
 }
 
-// `rank` non-null: also rank every pixel's scores inside the volume kernel (see t256_consume), fill *rank with the
-// buffers the later passes need and STOP after the volume kernel -- the caller runs rank_merge_f32, then
-// ncc_fast_fixup_ranked (which needs the merged best scores), then rank_resolve_f32.  `out` may then be null (no
-// volume is materialised).  rank->eps is an input: the re-ranking margin the partials are flagged against.
+// `rank` non-null (in: eps, idx, best -- best may be null): the all-D kernel computes the volume (`out` may be null:
+// nothing is materialised then), ranks every pixel's scores in LDS and writes idx / best / work-list flags itself;
+// *rank comes back filled with the buffers the later passes need and the call STOPS after that kernel -- the caller
+// runs ncc_fast_fixup_ranked (which needs the best scores and indices), then rank_resolve_f32.
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
@@ -1915,12 +2231,15 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   size_t need = ws.bytes;
   if (rank) {
-    const float eps = rank->eps;
+    const RankPlan in = *rank;
     *rank = rank_plan(workspace, ws.bytes, frames, H, W, D);
-    rank->eps = eps;
+    rank->eps = in.eps;
+    rank->idx = in.idx;
+    rank->best = in.best ? in.best : rank->best_scratch;
     need = rank->bytes;
   }
   if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
+  if (rank && !rank->idx) return CTD_ERR_INVALID_ARG;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
   // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
@@ -1943,8 +2262,8 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
                       (unsigned*)workspace, stream);
 }
 
-// Second half of a ranked call, after rank_merge_f32: fix-up of the listed windows (volume patch when there is one,
-// run values) with every recomputed score held against the merged `best` of its pixel.
+// Second half of a ranked call, after the all-D kernel: fix-up of the listed windows (volume patch when there is one,
+// run values) with every recomputed score held against the `best` / `idx` of its pixel.
 int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,
                           int D, int bs, void* workspace, const RankPlan& rank, const float* best, hipStream_t stream) {
   const bool per_frame = in1_frame_stride != 0;

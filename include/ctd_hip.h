@@ -38,7 +38,7 @@ enum ctd_status {
   CTD_ERR_HIP = 1000           /* 1000 + hipError_t of the failing runtime call           */
 };
 
-int ctd_version(void);                       /* ABI version, currently 1 */
+int ctd_version(void);                       /* ABI version, currently 2 (2: ranked argmax inside the all-D volume kernel; its workspace is ctd_xcorrvol_argmax_workspace_bytes()) */
 const char* ctd_status_string(int status);
 
 /* --------------------------------------------------------------------------------------
