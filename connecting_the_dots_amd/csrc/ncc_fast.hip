@@ -53,7 +53,7 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
 constexpr int kSTW = 64, kSTH = 16, kSRows = 4;
-constexpr double kDevFloor = 6e-3;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 3e-4 (ncc_inv_norm)
+constexpr double kDevFloor = 7e-2;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 2.1e-6 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
 // out_mean = mean_scale * (window mean - cval), out_dev = 1 / sqrt(sum of squared deviations) (0: listed window), out_img = img - cval
@@ -634,15 +634,13 @@ __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__
   }
 }
 
-// 1 / (sa * sb + 1e-8) from the RECIPROCAL deviations the pre-pass stores: t = ra * rb, times (1 - 1e-8 t), the
-// first two terms of 1 / (1 + 1e-8 t): three full-rate instructions instead of an fma, a quarter-rate v_rcp_f32
-// (9.3 cycles per wave against 2.7 for a 4-byte VOP2 and 4.2 for an 8-byte VOP3, tools/ubench.hip) and a multiply.
-// The neglected terms are (1e-8 t)^2 relative: below 1e-7 because the pre-pass lists every window whose deviation is
-// under kDevFloor (t <= 1 / kDevFloor^2), and listed windows go through the fix-up pass.
-__device__ inline float ncc_inv_norm(float ra, float rb) {
-  const float t = ra * rb;
-  return t * fmaf(t, -1e-8f, 1.f);
-}
+// 1 / (sa * sb + 1e-8) from the RECIPROCAL deviations the pre-pass stores: t = ra * rb, ONE multiply.  The reference's
+// 1e-8 changes the quotient by the relative amount 1e-8 * t: below 2.1e-6 because the pre-pass lists every window whose
+// deviation is under kDevFloor = 7e-2 (t <= 1 / kDevFloor^2 = 204), and listed windows go through the fix-up pass in the
+// reference's own arithmetic.  (Until round 3 the first-order term t * (1 - 1e-8 t) was kept and the floor was 6e-3:
+// two more instructions on each of the eight scores of a lane and row -- 10 % of the volume kernels' vector work, which
+// is what bounds the all-D kernel; LCN'd images have t ~ 0.01, where the term is 1e-10.)
+__device__ inline float ncc_inv_norm(float ra, float rb) { return ra * rb; }
 
 // cross-lane helpers (wave64) -----------------------------------------------------------
 __device__ inline float lane_prev1(float x) {   // result[l] = x[l-1]
@@ -1514,7 +1512,7 @@ __global__ __launch_bounds__(64 * (kTWaves + 1), 4) void ncc_fast_t256_kernel(
 // Same consumer pipeline as the tile-256 kernel, but ONE workgroup owns a (256-column tile, band of rows, frame) for
 // EVERY disparity: 15 consumer wavefronts + 1 loader (1024 threads, one workgroup per CU = four wavefronts on every
 // SIMD), 2 disparities per lane, so a pass over the band covers up to 30 disparities and the workgroup makes
-// ceil(D / 30) passes (the disparities are dealt evenly: D = 128 -> 5 passes of 26 on 13 wavefronts).  What that buys:
+// ceil(D / 30) passes (dealt evenly: D = 128 -> 5 passes of 26 on 13 wavefronts, see alld_plan).  What that buys:
 //   * the ranking state lives in LDS for the whole band -- two u32 slots {top, runner-up} per pixel, fed by LDS
 //     atomics from all consumer wavefronts across all passes -- and what leaves the kernel is the final index (int64),
 //     the best score, the work-list flag: no per-group partial planes (141 MB at config 2) and no merge kernel;
@@ -1563,7 +1561,7 @@ __device__ inline unsigned key_margin_units(float eps) { return (unsigned)ceilf(
 template <bool STORE, int KS>
 __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, float* __restrict__ out, int WAVE, int f,
                                              int lane, int w_lo, int h_lo, int h_hi, int r_begin, int n_iters,
-                                             int n_pass, int dgs, int H, int W, int D) {
+                                             int n_pass, int rot, int dgs, int H, int W, int D) {
   constexpr int TAIL = 4, STEP = 6, CPI = STEP / kARows;          // block size 9
   static_assert(STEP % kARows == 0, "a chunk never straddles two outer iterations");
   const long HW = (long)H * W;
@@ -1605,7 +1603,8 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
   int slot = 0;                                                    // ring slot of the current chunk
   f32x4 qa, qb0, qb1;                                              // value quads of the row (frame, pattern x 2)
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int d_base = pass * dgs + WAVE * 2;
+    const int grp = pass + rot >= n_pass ? pass + rot - n_pass : pass + rot;
+    const int d_base = grp * dgs + WAVE * 2;
     if (WAVE * 2 >= dgs || d_base >= D) {
       // a wavefront without disparities in this pass (the pass is narrower than 15 pairs, or it is the last pass and
       // both disparities lie past D): keep the barrier protocol, skip the work
@@ -1767,23 +1766,33 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
     float* __restrict__ out, int64_t* __restrict__ idx_out, float* __restrict__ best_out,
-    unsigned char* __restrict__ flags_out, WorkList work, float rank_eps, int H, int W, int D, int band_rows, int n_pass,
-    int dgs, int Wp, int W1, int xoff) {
+    unsigned char* __restrict__ flags_out, WorkList work, float rank_eps, int frames, int n_items, int H, int W, int D,
+    int band_rows, int n_pass, int dgs, int Wp, int W1, int xoff) {
   constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / kARows;
   // [band_rows][top | second][256] rank slots first (their row base goes into one lane register), then the staging ring
   extern __shared__ float lds_all[];
   unsigned* rank_lds = (unsigned*)lds_all;
   float* lds = lds_all + band_rows * 512;                          // [kABufs][kARows][kAPack]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int f = blockIdx.z;
-  const int w_lo = blockIdx.x * 256;
-  const int h_lo = blockIdx.y * band_rows;
+  // Work item of this workgroup: column tile fastest, then band, then frame.  (XCD-aware orders -- every XCD a
+  // contiguous range of the band-major list, so that co-resident workgroups share pattern rows in its L2 -- cut the
+  // operand fetches from 2 x 99 to 2 x 59-68 MiB and were 1-2.5 % SLOWER in four A/B runs: the kernel is bound by vector
+  // issue, not by its 5-10 % of operand traffic.  Pass order rotated per workgroup: slower as well.)
+  const int item = (int)blockIdx.x;
+  if (item >= n_items) return;                                     // whole workgroup, before any barrier
+  const int n_tiles = (W + 255) / 256;
+  const int n_bands = n_items / (frames * n_tiles);
+  const int w_lo = (item % n_tiles) * 256;
+  const int band = (item / n_tiles) % n_bands;
+  const int f = item / (n_tiles * n_bands);
+  const int h_lo = band * band_rows;
   const int h_hi = min(h_lo + band_rows, H);
   const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
   const int n_rows = r_end - r_begin + 1;
   const int n_iters = (n_rows + STEP - 1) / STEP;
   const int n_chunks = n_iters * CPI;                              // per pass; even
   const int n_act = dgs / 2;                                       // consumer wavefronts with work
+  const int rot = 0;                                               // first disparity group of this workgroup (pass p works on group (p + rot) % n_pass)
 
   // every wavefront clears its share of the rank slots (key 0 = below every score)
   for (int k = threadIdx.x; k < band_rows * 128; k += 64 * (kAWaves + 1)) ((uint4*)rank_lds)[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -1806,13 +1815,16 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;                 // the next chunk to issue: ring slot, pass, chunk in the pass
     auto issue_chunk = [&]() {
       float* buf = lds + i_slot * (kARows * kAPack);
-      const int xb = c_lo - (i_pass * dgs + dgs - 1);              // unclamped pattern column of span slot 0
+      const int i_grp = i_pass + rot >= n_pass ? i_pass + rot - n_pass : i_pass + rot;
+      const int xb = c_lo - (i_grp * dgs + dgs - 1);               // unclamped pattern column of span slot 0
       const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
 #pragma unroll
       for (int s = 0; s < kARows; ++s) {
         const int r = r_begin + i_ch * kARows + s;
         const int rc = clampi(r, 0, H - 1);
-        const int hs = clampi(r - TAIL, 0, H - 1);
+        // statistics of output row r - TAIL; product rows that complete no output of the band re-read a row the band
+        // needs anyway (no cache lines of their own)
+        const int hs = clampi(r - TAIL, h_lo, h_hi - 1);
         float* pk = buf + s * kAPack;
         dma_quad(a_img + (long)rc * Wp + aq0, pk);
         dma_quad(m0i + (long)hs * Wp + aq0, pk + kAA);
@@ -1912,9 +1924,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
 
   // two copies of the consumer loop: the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * wave) % 4
   if ((dgs - 2 - 2 * wave) & 2)
-    alld_consume<STORE, 2>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, dgs, H, W, D);
+    alld_consume<STORE, 2>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
   else
-    alld_consume<STORE, 0>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, dgs, H, W, D);
+    alld_consume<STORE, 0>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
 
   // ---- emit: the band's final {top, second} -> index, best score, work-list flag.  The last chunk barrier (behind
   // every wavefront's lgkmcnt(0)) has made all slot updates visible.
@@ -2055,6 +2067,10 @@ struct AlldPlan {
 };
 static AlldPlan alld_plan(int frames, int H, int W, int D) {
   AlldPlan ap;
+  // The disparities are dealt evenly over the ceil(D / 30) passes (D = 128: 5 x 26 on 13 wavefronts).  Four full passes
+  // of 30 and a last one of 8 measured 4 % SLOWER: a pass costs about the same whether 13 or 15 wavefronts work in it
+  // (the row's dependent chain and the chunk barrier, not the sum of the wavefronts' instructions), so the short pass
+  // is a whole pass's time for a quarter of its outputs.
   ap.n_pass = ceil_div(D, kADGMax);
   ap.dgs = 2 * ceil_div(ceil_div(D, 2), ap.n_pass);
   const long base = (long)ceil_div(W, 256) * frames;
@@ -2115,12 +2131,14 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
   if (rank) {
     // ranked call: the all-D kernel (one workgroup per column tile, band and frame, every disparity)
     const AlldPlan ap = alld_plan(frames, H, W, D);
-    dim3 grid(ceil_div(W, 256), ap.bands, frames), block(64 * (kAWaves + 1));
+    const int n_items = ceil_div(W, 256) * ap.bands * frames;
+    dim3 grid(n_items), block(64 * (kAWaves + 1));
     auto kern = out ? ncc_fast_alld_kernel<true> : ncc_fast_alld_kernel<false>;
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ap.lds));
     timing_begin(stream);
     hipLaunchKernelGGL(kern, grid, block, ap.lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
-                       rank->idx, rank->best, rank->flags, rank->work, rank->eps, H, W, D, ap.band_rows, ap.n_pass, ap.dgs,
+                       rank->idx, rank->best, rank->flags, rank->work, rank->eps, frames, n_items, H, W, D, ap.band_rows,
+                       ap.n_pass, ap.dgs,
                        ws.Wp, ws.W1, ws.xoff);
     timing_end(stream, W);
     CTD_LAUNCH_CHECK();
