@@ -52,25 +52,18 @@ def parse_args():
     return ap.parse_args()
 
 
-def self_launch(args):
+def check_gpu_count(n_ranks, backend, n_devices):
+    """--gpus N over RCCL needs N devices (connecting_the_dots_amd.sharding.check_gpu_count)."""
+    from connecting_the_dots_amd import sharding
+    err = sharding.check_gpu_count(n_ranks, backend, n_devices, what="--gpus")
+    return ("bench.py: " + err) if err else None
+
+
+def self_launch(args, deadline_s=None):
     """--gpus N without a launcher: start N ranks (fresh interpreters; this parent has not touched a GPU), relay
-    rank 0's output, exit with the worst return code."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    rank 0's output, exit non-zero if any rank failed or the deadline passed (sharding.launch_ranks)."""
+    from connecting_the_dots_amd import sharding
+    return sharding.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, deadline_s)
 
 
 def make_inputs(frames, rank, device):
@@ -174,14 +167,25 @@ def cpu_baseline(pattern_lcn_cpu, frames_lcn_cpu):
 def measured_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc
     passes of tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
-    WRITE_SIZE as is, both in KiB).  None when no profile of this build has been committed."""
+    WRITE_SIZE as is, both in KiB) and the file it was read from.  (None, None) when no profile of this build has
+    been committed: the counters are NOT collected in this run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-    if not files:
-        return None
-    for name, c in json.load(open(files[-1])).items():
-        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    for f in reversed(files):
+        for name, c in json.load(open(f)).items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "profiles/" + os.path.basename(f)
+    return None, None
+
+
+def committed_number(fname, key):
+    """A number recorded by a committed profile (profiles/<fname>, a `key = value` line): read, not measured here."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", fname)):
+            if line.strip().startswith(key):
+                return float(line.split("=", 1)[1].split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
     return None
 
 
@@ -221,7 +225,7 @@ def also_measured(te, L, frames, pat_lcn, args):
     ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
     units = args.frames * H * cols.value * D
-    plain = {"kernel": "ncc_fast_t256_kernel (volume only)", "avg_launch_ms": ms.value, "launches": n,
+    plain = {"kernel": "ncc_fast_t256_kernel (volume only, what ctd_xcorrvol_f32 launches)", "avg_launch_ms": ms.value, "launches": n,
              "achieved_GBs": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 if n else None,
              "frac_of_hbm_peak": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
     for _ in range(80):
@@ -235,7 +239,9 @@ def also_measured(te, L, frames, pat_lcn, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     fused = {"what": "LCN -> NCC -> argmax with reference indices, no volume materialised", "ms_per_step": dt * 1e3,
-             "value": args.frames * H * W * D / dt / 1e6, "unit": "Mpix*disp/s"}
+             "value": args.frames * H * W * D / dt / 1e6, "unit": "Mpix*disp/s",
+             "valu_busy": committed_number("round3_sq_counters_volume_free.txt", "valu_busy"),
+             "valu_busy_source": "profiles/round3_sq_counters_volume_free.txt (SQ pass of tools/pmc.sh on the no-store all-D kernel, committed)"}
     return {"volume_kernel_alone": plain, "fused_volume_free": fused}
 
 
@@ -253,12 +259,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer GPUs than ranks
+    backend = os.environ.get("CTD_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" for rehearsals
+    err = check_gpu_count(world, backend, torch.cuda.device_count())
+    if err:
+        raise SystemExit(err)
+    # one rank per GPU; the modulo only matters for the gloo rehearsal of the N > 1 path on a box with fewer GPUs
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    backend = os.environ.get("CTD_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -325,10 +334,22 @@ def main():
     # when it idles that long and then needs some 25 steps to get them back (measured: with the collector run between
     # the settle loop and 5 warm-up steps the 14 ms timed region came out 13 % slower, its dominant kernel 0.46
     # instead of 0.40 ms; with 25 warm-up steps it did not).
+    # The cold number first: W warm-up steps and K timed steps straight after start-up, before any settling -- what a
+    # caller sees who runs the contract's command on an idle card (clocks still ramping, code objects and allocator
+    # pools freshly touched).  Reported as `cold_ms_per_step` next to the steady-state `ms_per_step`.
+    L.ctd_kernel_timing_enable(2 * (args.steps + args.warmup) + 16)   # (the argument also sizes the event pool)
+    for _ in range(args.warmup):
+        step(exchange=False)
+    torch.cuda.synchronize()
+    t_c = time.perf_counter()
+    for _ in range(args.steps):
+        held = step(exchange=False)
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t_c) / args.steps * 1e3
+    L.ctd_kernel_timing_collect(None, None)
     import gc
     gc.collect()
     gc.disable()                                  # no collector pauses from here to the end of the timed region
-    L.ctd_kernel_timing_enable(1)                 # settle and warm-up steps run exactly what the timed steps run
     prev, settle_steps, t_settle = None, 0, time.perf_counter()
     for _ in range(100):
         t_s = time.perf_counter()
@@ -359,7 +380,7 @@ def main():
     # run-to-run spread: two more regions of the same K steps (reported next to the headline one, never instead of it)
     repeats = []
     if not args.headline_only:
-        L.ctd_kernel_timing_enable(1)             # same instrumentation as the headline region
+        L.ctd_kernel_timing_enable(2 * args.steps + 16)   # same instrumentation as the headline region
         for _ in range(2):
             barrier()
             t_r = time.perf_counter()
@@ -395,6 +416,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "cold_ms_per_step": cold_ms,
             "repeat_ms_per_step": repeats,
             "settle_steps": settle_steps,
             "higher_is_better": True,
@@ -416,9 +438,16 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "avg_launch_ms": avg_ms.value, "launches": n_launch,
                 "algorithmic_bytes_per_launch": kernel_units * BYTES_PER_PIXDISP,
-                "traffic": measured_traffic(kernel),
             },
         }
+        traffic, traffic_src = measured_traffic(kernel)
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_source"] = (traffic_src + " (rocprofv3 --pmc passes of this build, committed; not collected in this run)") if traffic_src else None
+        # second denominator: what a kernel that does nothing but this kernel's stores reaches on this card
+        ceil_tbs = committed_number("round3_store_ceiling_summary.txt", "all_d_pattern_store_only_TBs")
+        if ceil_tbs and achieved:
+            out["roofline"]["store_only_ceiling"] = {"GBs": ceil_tbs * 1e3, "frac_of_it": achieved / (ceil_tbs * 1e3),
+                                                     "source": "profiles/round3_store_ceiling_summary.txt (tools/ubench_src/store_ceiling.hip)"}
         if geo is not None and n_exchanged[0]:
             last = ring[(n_exchanged[0] - 1) % len(ring)]
             if last[1] is not None:

@@ -56,7 +56,8 @@ void ctd_kernel_timing_enable(int enable) {
     // allocates an event's signal at its first record, and that must not happen between the start event and the
     // kernel it brackets
     bool fresh = false;
-    while (g_pool.size() < 128) {
+    const size_t want = enable > 128 ? (size_t)enable : 128;          // `enable` doubles as the number of events to hold ready
+    while (g_pool.size() < want) {
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break;
       (void)hipEventRecord(e, nullptr);

@@ -8,8 +8,79 @@ denominator separately -- the mean of per-rank ratios is not the batch value.
 
 One process per GPU, `torch.distributed` ("nccl" is RCCL over xGMI on ROCm; "gloo" in CPU tests).
 """
+import os
+import subprocess
+import sys
+import time
+
 import torch
 import torch.distributed as dist
+
+
+def check_gpu_count(n_ranks, backend, n_devices, what="--gpus"):
+    """N ranks over RCCL need N devices: two ranks on one device fail late ("duplicate GPU") or hang.  The gloo
+    rehearsal (CTD_DIST_BACKEND=gloo) may oversubscribe a device on purpose.  Returns an error text or None."""
+    if backend == "nccl" and n_ranks > n_devices:
+        return ("%s %d over RCCL needs %d visible GPUs, this box has %d (rehearse more ranks than GPUs with "
+                "CTD_DIST_BACKEND=gloo)" % (what, n_ranks, n_ranks, n_devices))
+    return None
+
+
+def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
+    """Start `n_ranks` fresh interpreters of `script` (one process per GPU; the caller has not touched a GPU and never
+    re-execs), rendezvous on 127.0.0.1, relay rank 0's stdout, return an exit code.  A rank that dies takes the others
+    down with it, and the whole launch has a deadline (CTD_BENCH_DEADLINE_S, default 900 s): no wedged rank keeps the
+    parent waiting."""
+    import socket
+    backend = os.environ.get("CTD_DIST_BACKEND", "nccl")
+    err = check_gpu_count(n_ranks, backend, torch.cuda.device_count())      # (counting devices does not initialise HIP)
+    if err:
+        sys.stderr.write("%s: %s\n" % (os.path.basename(script), err))
+        return 2
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("CTD_BENCH_DEADLINE_S", "900"))
+    # the port is bound here and released right before the ranks start; a rendezvous that loses the race fails fast
+    # (rank 0 cannot bind) and the loop below then ends the other ranks
+    s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=(subprocess.PIPE if capture_rank0 else None) if r == 0 else subprocess.DEVNULL))
+    t_end = time.monotonic() + deadline_s
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.monotonic() > t_end:
+            failed = ("rank %d exited with code %d" % (bad[0], rcs[bad[0]])) if bad else "deadline of %.0f s passed" % deadline_s
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else b""
+    for p in procs:
+        p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if failed:
+        sys.stderr.write("%s: %s; the remaining ranks were stopped\n" % (os.path.basename(script), failed))
+        return 1
+    return max(abs(p.returncode) for p in procs)
 
 
 def frame_shard(n_frames, rank=None, world_size=None):
@@ -36,6 +107,25 @@ def reduce_ratio(numerator, denominator, group=None):
     else:
         total = local
     return total[0] / total[1]
+
+
+def reduce_ratio_ddp(numerator, denominator, group=None):
+    """The same global ratio for a loss term of a DistributedDataParallel step.  DDP AVERAGES the ranks' gradients, so
+    a term whose batch value is `sum_r(num_r) / sum_r(den_r)` (model/networks.py:377: the mask-weighted photometric
+    mean; also any mean over a per-rank varying number of samples) must hand DDP the local gradient
+    `world * d num_r / DEN`: averaged over the ranks that is `sum_r(d num_r) / DEN`, the gradient of the reference's
+    single-process batch.  Value: the global ratio on every rank (what the reference logs); the denominator carries
+    no gradient (in the reference it is the LCN std of the input, or a sample count)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return numerator.reshape(()) / denominator.reshape(())
+    world = dist.get_world_size(group)
+    local = torch.stack([numerator.reshape(()), denominator.reshape(())]).detach()
+    total = local.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    total = total.to(numerator.device)
+    den = total[1].clamp_min(torch.finfo(total.dtype).tiny)
+    grad_path = numerator.reshape(()) * (float(world) / den)
+    return grad_path + (total[0] / den - grad_path.detach())
 
 
 def reduce_mean(value, count, group=None):

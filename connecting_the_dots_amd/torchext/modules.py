@@ -123,6 +123,16 @@ class MultiScalePatternSimilarityLoss(torch.nn.Module):
                                             self.loss_eps)
         return vals, projs
 
+    def terms(self, disps, ims, stds=None):
+        """(terms [n_scales, 3] = (numerator, denominator, ratio) per scale, [pattern_proj per scale]): numerator and
+        denominator of every scale's masked mean, for the cross-rank ratio of sums (sharding.reduce_ratio_ddp)."""
+        n = len(self.patterns)
+        stds = list(stds) if stds is not None else [None] * n
+        self.patterns = [p.to(disps[0].device) for p in self.patterns]
+        _, terms, projs = pattern_loss_multi(list(disps), list(ims), stds, self.patterns, self.loss_type,  # noqa: F405
+                                             self.loss_eps)
+        return terms, projs
+
 
 class DispToDepth(torch.nn.Module):
     """`networks.DispToDepth(focal_length, baseline)` (model/networks.py:313-321), one fused kernel each way."""

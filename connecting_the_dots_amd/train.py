@@ -82,7 +82,7 @@ class DisparityTrainer:
         """exp_synph.py:106-118 (single scale): photometric term + dp_weight * disparity term"""
         if self.pg is not None:
             num, den, _ = self.photo.terms(disp, im_lcn, std)
-            photo = sharding.reduce_ratio(num, den, self.pg)          # ratio of all-reduced sums (networks.py:377)
+            photo = sharding.reduce_ratio_ddp(num, den, self.pg)      # ratio of all-reduced sums (networks.py:377)
         else:
             photo, _ = self.photo(disp, im_lcn, std)
         vals = [photo]
@@ -135,7 +135,12 @@ class TrackTrainer:
     two-view geometric loss on disparity -> depth, weighted `ge_weight / (tl (tl-1) / 2)`.
 
     Data parallel: wrap happens here (`torch.nn.parallel.DistributedDataParallel`, bucketed gradient all-reduce
-    overlapped with backward, RCCL); every loss term is a per-rank mean over the rank's own samples, as DDP assumes.
+    overlapped with backward, RCCL).  DDP averages the ranks' gradients; the terms that are plain means over equal
+    shards (disparity loss, geometric loss) need nothing more, the two that are RATIOS OF SUMS over the batch -- the
+    mask-weighted photometric mean (networks.py:377) and the edge loss over the supervised samples only
+    (exp_synph.py:120-131), whose count differs from rank to rank -- reduce numerator and denominator across the ranks
+    (`sharding.reduce_ratio_ddp`: value = the reference's batch value on every rank, averaged gradient = the reference's
+    batch gradient).  `tests/test_config5_ddp_gpu.py` holds a two-rank step against the one-process step on the joined batch.
     """
 
     def __init__(self, net, patterns, K, baseline, focal_lengths, dp_weight=0.02, ge_weight=0.1, train_edge=-1, lr=1e-4,
@@ -182,17 +187,29 @@ class TrackTrainer:
         disps, edges = out
         tl, B = data["im0"].shape[:2]
         n = len(self.imsizes)
-        vals = list(self.photo(disps, [data["lcn%d" % s] for s in range(n)], [data["std%d" % s] for s in range(n)])[0])
+        lcns, stds = [data["lcn%d" % s] for s in range(n)], [data["std%d" % s] for s in range(n)]
+        if self.pg is not None:
+            terms, _ = self.photo.terms(disps, lcns, stds)                        # [n, 3]: numerator, denominator, ratio
+            vals = [sharding.reduce_ratio_ddp(terms[s, 0], terms[s, 1], self.pg) for s in range(n)]
+        else:
+            vals = list(self.photo(disps, lcns, stds)[0])
         if self.dp_weight > 0:
             vals.append(self.disparity_loss(disps[0], 1 - torch.sigmoid(edges[0])) * self.dp_weight)
-        sup = data["id"] > self.train_edge                                        # [B]
+        # Edge loss on the supervised samples (exp_synph.py:120-131: `edge_loss(e[mask], grad[mask])`, zero when the
+        # mask is empty) as a mask-weighted mean: no host round trip to look at the mask, and a rank without a supervised
+        # sample still sends (zero) gradients to every edge-decoder parameter, which DDP requires of every step.
+        sup = (data["id"] > self.train_edge).to(torch.float32).view(1, B, 1, 1, 1)
         for s, e in enumerate(edges):
-            if bool(sup.any()):
-                e5 = e.view(tl, B, *e.shape[1:])[:, sup]
-                gt = (data["grad%d" % s] < 0.2).to(torch.float32)[:, sup]         # inverse edge map: 0 = edge
-                vals.append(self.edge_loss(e5.reshape(-1, *e5.shape[2:]), gt.reshape(-1, *gt.shape[2:])))
+            e5 = e.view(tl, B, *e.shape[1:])
+            gt = (data["grad%d" % s] < 0.2).to(torch.float32)                     # inverse edge map: 0 = edge
+            bce = torch.nn.functional.binary_cross_entropy_with_logits(e5, gt, pos_weight=self.edge_loss.pos_weight,
+                                                                       reduction="none")
+            num = (bce * sup).sum()
+            cnt = sup.sum() * float(tl * e5[0, 0].numel())
+            if self.pg is not None:
+                vals.append(sharding.reduce_ratio_ddp(num, cnt, self.pg))
             else:
-                vals.append(torch.zeros_like(vals[0]))
+                vals.append(num / cnt.clamp_min(1.0))
         if not train:
             return vals
         ge_num = tl * (tl - 1) / 2
@@ -205,6 +222,25 @@ class TrackTrainer:
                                     R[i1].contiguous(), t[i1].contiguous())
                     vals.append(v * (self.ge_weight / ge_num))
         return vals
+
+    @torch.no_grad()
+    def evaluate(self, batch, metric=None):
+        """The test pass of the reference (`Worker.test_epoch`, torchext/worker.py:464-500, with the callbacks of
+        exp_synph.py:201-224): forward without gradients, the loss terms of `loss_forward(train=False)` (no geometric
+        terms), and the disparity error of scale 0 against `batch["disp0"]` [tl, B, 1, H, W] on the evaluation crop.
+        Returns (loss values, metric dict); pass a `DisparityMetric` to accumulate over several batches."""
+        was_training = self.net.training
+        self.net.eval()
+        try:
+            data = self.copy_data(batch)
+            out = self.net(torch.cat((data["lcn0"], data["im0"].reshape(-1, *data["im0"].shape[2:])), dim=1))
+            vals = self.loss_forward(out, data, train=False)
+            metric = metric if metric is not None else DisparityMetric()
+            es = out[0][0]
+            metric.add(es, batch["disp0"].reshape(es.shape).to(es.dtype))
+        finally:
+            self.net.train(was_training)
+        return [float(v) for v in vals], metric.get()
 
     def train_step(self, batch):
         w = self.watch
@@ -228,3 +264,40 @@ class TrackTrainer:
         w.stop("optimizer")
         w.stop("total", sync=False)
         return [float(v.detach()) for v in vals]
+
+
+class DisparityMetric:
+    """Disparity error of the evaluation pass: the reference's `co.metric.MultipleMetric(DistanceMetric(vec_length=1),
+    OutlierFractionMetric(vec_length=1, thresholds=[0.1, 0.5, 1, 2, 5]))` (model/exp_synph.py:201-205,
+    co/metric.py:76-129) on the region where the reference evaluates, rows 13 .. H-13 and columns 140 .. W-13
+    (exp_synph.py:46-50, `crop_output` :226-232), over the pixels with ground truth (`gt > 0`, exp_synph.py:147).
+    Same keys as `metric.get()` there: dist2_mean / _std / _median / _q10 / _q90 / _min / _max and of<threshold>.
+    Distances are gathered on the device; `get()` evaluates them once."""
+
+    THRESHOLDS = (0.1, 0.5, 1, 2, 5)
+
+    def __init__(self, crop=(13, 13, 140, 13)):
+        self.crop = crop                      # rows cut at the top / bottom, columns cut at the left / right
+        self.dists = []
+
+    def reset(self):
+        self.dists = []
+
+    def add(self, es, gt):
+        """es, gt [..., H, W] estimated and ground-truth disparity of scale 0"""
+        t, b, l, r = self.crop
+        H, W = es.shape[-2:]
+        es, gt = es[..., t:H - b, l:W - r], gt[..., t:H - b, l:W - r]
+        self.dists.append((es - gt).abs()[gt > 0].reshape(-1).to(torch.float32))
+
+    def get(self):
+        d = torch.cat(self.dists).double()
+        if d.numel() == 0:
+            return {}
+        q = torch.quantile(d, torch.tensor([0.1, 0.5, 0.9], dtype=d.dtype, device=d.device)) if d.numel() <= (1 << 24) \
+            else torch.tensor([float("nan")] * 3)
+        out = {"dist2_mean": float(d.mean()), "dist2_std": float(d.std(unbiased=False)), "dist2_median": float(q[1]),
+               "dist2_q10": float(q[0]), "dist2_q90": float(q[2]), "dist2_min": float(d.min()), "dist2_max": float(d.max())}
+        for t in self.THRESHOLDS:
+            out["of%s" % t] = float((d > t).double().mean())
+        return out

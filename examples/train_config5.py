@@ -29,15 +29,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # self-launch: this parent never touches a GPU
-        import socket
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(args.gpus)]
-        sys.exit(max(abs(p.wait()) for p in procs))
+        from connecting_the_dots_amd import sharding
+        sys.exit(sharding.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, capture_rank0=False))
 
     import numpy as np
     import torch
@@ -47,7 +40,11 @@ def main():
     from connecting_the_dots_amd.train import StopWatch, TrackTrainer
     from tests import workloads
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    from connecting_the_dots_amd import sharding
+    err = sharding.check_gpu_count(world, os.environ.get("CTD_DIST_BACKEND", "nccl"), torch.cuda.device_count())
+    if err:
+        raise SystemExit("train_config5.py: " + err)
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()     # (modulo: gloo rehearsal only)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     pg = None
@@ -84,6 +81,9 @@ def main():
         print("config 5: %d GPU(s) x batch %d x track %d at %dx%d: %.2f it/s, %.1f frames/s | ms per step: %s" % (
             world, args.batch, TL, H, W, 1e3 / ms["total"], world * args.batch * TL * 1e3 / ms["total"],
             ", ".join("%s %.2f" % kv for kv in ms.items())), flush=True)
+        # the reference's test pass (exp_synph.py:201-224): disparity error of scale 0 on the evaluation crop
+        ev_vals, metric = tr.evaluate(batches[0])
+        print("evaluate: loss %.5f | %s" % (sum(ev_vals), ", ".join("%s=%.4f" % kv for kv in metric.items())), flush=True)
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

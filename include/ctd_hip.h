@@ -51,6 +51,8 @@ const char* ctd_status_string(int status);
  * `columns` receives the number of output columns per row that kernel covers (the
  * remaining W - columns are produced by a secondary kernel), so that the caller can
  * price the launch in algorithmic bytes.  Not thread-safe; meant for one bench process.
+ * `enable` > 1 also says how many events to hold ready (two per launch until the next
+ * collect; 128 by default): none is created or first recorded between two launches then.
  * -------------------------------------------------------------------------------------- */
 void ctd_kernel_timing_enable(int enable);
 int ctd_kernel_timing_collect(double* avg_ms, int* columns);
@@ -104,20 +106,26 @@ int ctd_argmax_disp_f32(const float* vol, int64_t* idx, float* best, int frames,
  *   best is the reference-order score.
  * CTD_NCC_FAST: every disparity whose fast score lies within `rerank_eps` of the pixel's
  *   best is re-scored in reference order, so the indices are those of the reference-order
- *   volume whenever |fast - exact| <= rerank_eps / 2 (rerank_eps < 0: plain argmax of the
- *   fast scores).  Where ctd_xcorrvol_rank_supported() holds (block 9, W % 4 == 0) the
- *   volume kernel ranks the scores itself (per-group top-2 partials, no second pass over
- *   the volume) and vol_out may be NULL: nothing is materialised then.  Otherwise vol_out
- *   is required (CTD_ERR_INVALID_ARG if NULL) and ranked in one more pass.  best = the
- *   fast score of idx, within 2^-20 relative of vol_out[idx] (the reference-order score
- *   for re-scored pixels when no volume is written).
+ *   volume whenever |fast - exact| <= rerank_eps / 2.  Where ctd_xcorrvol_rank_supported()
+ *   holds (block 9, W % 4 == 0, D <= 512) the all-D volume kernel ranks the scores itself:
+ *   one workgroup walks every disparity of its (column tile, band, frame) and keeps the best
+ *   and the runner-up of every pixel in LDS, so idx / best leave that kernel directly (no
+ *   partial planes, no second pass over the volume) and vol_out may be NULL: nothing is
+ *   materialised then.  Otherwise vol_out is required (CTD_ERR_INVALID_ARG if NULL) and
+ *   ranked in one more pass.  best = the fast score of idx to within 2.4e-7 absolute (the
+ *   ranking keys are fixed point, 2^-21 apart; it is the reference-order score for re-scored
+ *   pixels when no volume is written).
+ *   rerank_eps < 0 = plain argmax of the fast scores, no exact re-scoring: defined on a
+ *   materialised volume (vol_out != NULL: the patched volume is ranked in one more pass);
+ *   without a volume a negative value is taken as 0.
  * Workspace: ctd_xcorrvol_argmax_workspace_bytes().
  * -------------------------------------------------------------------------------------- */
 int ctd_xcorrvol_rank_supported(int C, int H, int W, int D, int block_size);
-/* Inspection aid for tests / tools: byte offsets, inside the workspace of a ranked ctd_xcorrvol_argmax_f32 call, of
- * offsets[0..3] = top-key plane ([frames][groups][H][W] f32), flag bytes [frames][H][W], the work-list counters (16 x
- * u32, 256 bytes apart, one per key = image row & 15) and the work list (i64 flat pixel indices, 16 segments of
- * ceil(frames * H / 16) * W entries, one per key); offsets[4] = number of disparity groups.  `offsets` has 5 entries. */
+/* Inspection aid for tests / tools: how a ranked ctd_xcorrvol_argmax_f32 call is laid out.  offsets[0] = rows per band
+ * of the all-D kernel, offsets[4] = its passes over the disparities; byte offsets inside the workspace of
+ * offsets[1] = flag bytes [frames][H][W], offsets[2] = the work-list counters (16 x u32, 256 bytes apart, one per key =
+ * image row & 15), offsets[3] = the work list (i64 flat pixel indices, 16 segments of ceil(frames * H / 16) * W entries,
+ * one per key).  `offsets` has 5 entries. */
 int ctd_xcorrvol_rank_layout(int frames, int H, int W, int D, int per_frame_pattern, size_t* offsets);
 size_t ctd_xcorrvol_argmax_workspace_bytes(int frames, int C, int H, int W, int D, int block_size, int algo);
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride,

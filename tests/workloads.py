@@ -131,7 +131,7 @@ def track_batch(seed, tl, B, H, W, D, n_scales=4, block=(48, 64)):
             ims[i, b, 0], d = synth_ir(pat, rs, D, block=block)
             disps[i, b, 0] = d
             R[i, b], t[i, b] = small_pose(rs)
-    out = {"id": np.arange(B, dtype=np.int64), "R": R, "t": t, "pattern": pat}
+    out = {"id": np.arange(B, dtype=np.int64), "R": R, "t": t, "pattern": pat, "disp0": disps}
     im, dd = ims, disps
     for s in range(n_scales):
         out["im%d" % s] = im
