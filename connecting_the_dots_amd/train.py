@@ -228,7 +228,9 @@ class TrackTrainer:
         """The test pass of the reference (`Worker.test_epoch`, torchext/worker.py:464-500, with the callbacks of
         exp_synph.py:201-224): forward without gradients, the loss terms of `loss_forward(train=False)` (no geometric
         terms), and the disparity error of scale 0 against `batch["disp0"]` [tl, B, 1, H, W] on the evaluation crop.
-        Returns (loss values, metric dict); pass a `DisparityMetric` to accumulate over several batches."""
+        Returns (loss values, metric dict); pass a `DisparityMetric` to accumulate over several batches.  With a
+        process group the loss terms reduce across the ranks (as in training): every rank has to make the call; the
+        metric is that of the rank's own shard."""
         was_training = self.net.training
         self.net.eval()
         try:

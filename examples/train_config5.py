@@ -81,8 +81,10 @@ def main():
         print("config 5: %d GPU(s) x batch %d x track %d at %dx%d: %.2f it/s, %.1f frames/s | ms per step: %s" % (
             world, args.batch, TL, H, W, 1e3 / ms["total"], world * args.batch * TL * 1e3 / ms["total"],
             ", ".join("%s %.2f" % kv for kv in ms.items())), flush=True)
-        # the reference's test pass (exp_synph.py:201-224): disparity error of scale 0 on the evaluation crop
-        ev_vals, metric = tr.evaluate(batches[0])
+    # the reference's test pass (exp_synph.py:201-224): disparity error of scale 0 on the evaluation crop.  Under DDP the
+    # loss terms reduce across the ranks, so EVERY rank runs it (on its own shard); rank 0 prints its shard's metric.
+    ev_vals, metric = tr.evaluate(batches[0])
+    if rank == 0:
         print("evaluate: loss %.5f | %s" % (sum(ev_vals), ", ".join("%s=%.4f" % kv for kv in metric.items())), flush=True)
     if pg is not None:
         torch.distributed.barrier()
