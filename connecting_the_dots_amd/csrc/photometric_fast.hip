@@ -23,6 +23,8 @@
 // sign() of the census-SAD gradient is discontinuous: where the fast diff is within 1e-6 of zero it is
 // recomputed with the reference's own operation chain, so the sign (hence the gradient) agrees with the
 // reference wherever the reference's sign is not itself decided by its last bit.
+#include <type_traits>
+
 #include "ctd_internal.h"
 
 namespace ctd {
@@ -711,6 +713,194 @@ __global__ __launch_bounds__(256) void costvol_fast_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Census TRANSFORM cost volume (types 2 / 3): the soft census term of a tap, h(P_d[tap] - P_d[centre]), does not
+// depend on d away from the right image border -- with x' = x - d it is the pattern's own census value
+//     CP(y, x'; dy, dx) = h(P[clamp(y+dy)][clamp(x'+dx)] - P[y][clamp(x')])        (x' may be negative: both clamps apply)
+// so it is evaluated once per pattern column and tap, not once per output and tap (the v_rsq_f32 leaves the disparity
+// loop: 81 per PATTERN PIXEL instead of 81 per output, D = 128..256 times fewer), and likewise CI(y, x; dy, dx) once
+// per image pixel.  Per tap the workgroup stages CI for its 64 x 2 pixels and CP for the 64 + 127 pattern columns its
+// 128 disparities reach (2 evaluations per thread), then every thread accumulates its 4 pixels x 16 disparities:
+//   census_sad: the values are staged as 24-bit FIXED POINT, u = round((t + 1) * 2^23) with t = des * rsq(des^2 + eps) in
+//     (-1, 1), and one v_sad_u32 per output and tap does |u_p - u_i| + acc (exact integer sum, 81 * 2^24 < 2^32; the
+//     rounding of a staged value is 2^-24, that of an f32 t 3e-8: the same accuracy);
+//   census_mse: staged as floats, one subtract and one fma per output and tap.
+// Only the HALF right-most image columns differ (there the tap column is clamped to W-1 BEFORE the shift by d, so the
+// term does depend on d): the workgroups of the last tile column recompute those outputs term by term afterwards.
+// Reference: torchext/ext/ext.h:244-259 (per-tap soft census), composition rule of SURVEY 8a/A6.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kCcW = 64, kCcR = 2, kCcD = 128, kCcDT = 16;   // pixel tile, disparities per workgroup / per thread
+
+__device__ inline unsigned sad_u32(unsigned a, unsigned b, unsigned acc) {   // |a - b| + acc in one VALU instruction (no builtin)
+  unsigned r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  return r;
+}
+
+template <int TYPE, int BS>
+__global__ __launch_bounds__(256) void costvol_census_kernel(const float* __restrict__ im, const float* __restrict__ pat,
+                                                             long pat_frame_stride, float* __restrict__ cost, int H, int W,
+                                                             int D, int n_chunks, float eps) {
+  static_assert(TYPE == 2 || TYPE == 3, "census types only");
+  constexpr int HALF = BS / 2, TH = kCcR + BS - 1, TW = kCcW + BS - 1;
+  constexpr int CPW = kCcW + kCcD;                  // staged pattern census columns j = x' - xp0, j in [0, CPW)
+  constexpr int SPW = CPW + BS - 1;                 // raw pattern span: column xp0 - HALF + s
+  typedef typename std::conditional<TYPE == 3, unsigned, float>::type cen_t;
+  __shared__ float sI[TH][TW];
+  __shared__ float sP[TH][SPW];
+  __shared__ __attribute__((aligned(16))) cen_t cI[2][kCcR][kCcW];
+  __shared__ __attribute__((aligned(16))) cen_t cP[2][kCcR][CPW];
+  const int t = threadIdx.x;
+  const int x0 = blockIdx.x * kCcW, y0 = blockIdx.y * kCcR;
+  const int f = blockIdx.z / n_chunks, d0 = (blockIdx.z - f * n_chunks) * kCcD;
+  const long HW = (long)H * W;
+  const float* ip = im + (long)f * HW;
+  const float* pp = pat + (long)f * pat_frame_stride;
+  const int xp0 = x0 - d0 - kCcD;                   // pattern column of census slot 0 (may be negative)
+  // raw tiles, both clamps baked in: image columns clamp(x0 - HALF + c), pattern columns clamp(xp0 - HALF + s)
+  for (int i0 = t; i0 < TH * TW; i0 += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + 256 * u, TH * TW - 1);
+      const int r = i / TW, c = i - r * TW;
+      v[u] = ip[(long)clampi(y0 + r - HALF, 0, H - 1) * W + clampi(x0 + c - HALF, 0, W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + 256 * u < TH * TW) (&sI[0][0])[i0 + 256 * u] = v[u];
+  }
+  for (int i0 = t; i0 < TH * SPW; i0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + 256 * u, TH * SPW - 1);
+      const int r = i / SPW, c = i - r * SPW;
+      v[u] = pp[(long)clampi(y0 + r - HALF, 0, H - 1) * W + clampi(xp0 + c - HALF, 0, W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 256 * u < TH * SPW) (&sP[0][0])[i0 + 256 * u] = v[u];
+  }
+  // this thread's outputs: pixel quad q of row `row`, disparities d0 + 16 g + k
+  const int q = t & 15, row = (t >> 4) & 1, g = t >> 5;
+  const int jb = 4 * q - kCcDT * g + kCcD - kCcDT;  // first staged pattern column of its five quads (multiple of 4)
+  // its two census evaluations per tap: element e = t and t + 256 of [image 2 x 64 | pattern 2 x CPW]
+  constexpr int NI = kCcR * kCcW;
+  static_assert(NI + kCcR * CPW == 512, "two staged census values per thread and tap");
+  typename std::conditional<TYPE == 3, unsigned, float>::type acc[4][kCcDT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < kCcDT; ++k) acc[i][k] = 0;
+  __syncthreads();
+  // centre values of the two elements (tap independent) and their tile coordinates
+  const bool e0_img = t < NI;                       // (NI = 128: the first two wavefronts; wave-uniform)
+  const int e0r = e0_img ? t / kCcW : (t - NI) / CPW, e0c = e0_img ? t % kCcW : (t - NI) % CPW;
+  const int e1 = t + 256 - NI, e1r = e1 / CPW, e1c = e1 % CPW;
+  const float c0 = e0_img ? sI[e0r + HALF][e0c + HALF] : sP[e0r + HALF][e0c + HALF];
+  const float c1 = sP[e1r + HALF][e1c + HALF];
+  auto soft = [&](float des) -> cen_t {
+    const float tt = des * __builtin_amdgcn_rsqf(fmaf(des, des, eps));      // 2 h(des) - 1, in (-1, 1)
+    if constexpr (TYPE == 3) return (unsigned)fmaf(tt, 8388608.f, 8388608.5f);   // round((tt + 1) * 2^23)
+    else return tt;
+  };
+  int buf = 0;
+#pragma unroll 1
+  for (int dy = 0; dy < BS; ++dy) {
+#pragma unroll 1
+    for (int dx = 0; dx < BS; ++dx) {
+      // stage this tap's census values (the buffer of the tap before last: every thread is past reading it, see below)
+      const float v0 = e0_img ? sI[e0r + dy][e0c + dx] : sP[e0r + dy][e0c + dx];
+      const float v1 = sP[e1r + dy][e1c + dx];
+      if (e0_img) cI[buf][e0r][e0c] = soft(v0 - c0);
+      else cP[buf][e0r][e0c] = soft(v0 - c0);
+      cP[buf][e1r][e1c] = soft(v1 - c1);
+      __syncthreads();                               // one barrier per tap: a thread that writes buffer b for tap n + 2 has
+                                                     // passed the barrier of tap n + 1, i.e. everybody finished reading tap n
+      typedef cen_t c4 __attribute__((ext_vector_type(4)));
+      const c4 ci = *(const c4*)&cI[buf][row][4 * q];
+      cen_t cp[20];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const c4 w4 = *(const c4*)&cP[buf][row][jb + 4 * m];
+        cp[4 * m] = w4[0]; cp[4 * m + 1] = w4[1]; cp[4 * m + 2] = w4[2]; cp[4 * m + 3] = w4[3];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < kCcDT; ++k) {
+          if constexpr (TYPE == 3) {
+            acc[i][k] = sad_u32(cp[i - k + kCcDT], ci[i], acc[i][k]);                    // |u_p - u_i| + acc
+          } else {
+            const float d2 = cp[i - k + kCcDT] - ci[i];
+            acc[i][k] = fmaf(d2, d2, acc[i][k]);
+          }
+        }
+      buf ^= 1;
+    }
+  }
+  // 2 (h_p - h_i) = t_p - t_i: census_sad 0.5 / bs^2 (and 2^-23 for the fixed point), census_mse 0.25 / bs^2
+  const float scale = TYPE == 3 ? 0.5f / (float)(BS * BS) / 8388608.f : 0.25f / (float)(BS * BS);
+  const int y = y0 + row, xq = x0 + 4 * q;
+  const int x_last_plain = W - 1 - (BS - 1 - HALF);  // right of it the first clamp makes the term depend on d
+  if (y < H) {
+#pragma unroll
+    for (int k = 0; k < kCcDT; ++k) {
+      const int d = d0 + kCcDT * g + k;
+      if (d >= D) break;
+      float* o = cost + ((long)f * D + d) * HW + (long)y * W + xq;
+      if (xq + 3 <= x_last_plain && (W & 3) == 0 && ((uintptr_t)cost & 15) == 0) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        *(f4*)o = f4{(float)acc[0][k] * scale, (float)acc[1][k] * scale, (float)acc[2][k] * scale, (float)acc[3][k] * scale};
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (xq + i <= x_last_plain) o[i] = (float)acc[i][k] * scale;
+      }
+    }
+  }
+  // the right-most columns, term by term (ext.h:244-259 order of clamps: tap column first, shift second): the
+  // workgroup's threads share them, pixel fastest
+  const int xb0 = max(x0, x_last_plain + 1), nb = min(x0 + kCcW, W) - xb0;
+  if (nb > 0) {
+    const int nd = min(kCcD, D - d0);
+    for (int o = t; o < nb * kCcR * nd; o += 256) {
+      const int px = o % nb, r = (o / nb) % kCcR, dd = o / (nb * kCcR);
+      const int x = xb0 + px, yy = y0 + r, d = d0 + dd;
+      if (yy >= H) continue;
+      // (span slots are addressed by the UNCLAMPED column, x - d >= xp0 + 1: the staged values carry the clamp)
+      const float ec = sP[r + HALF][x - d - xp0 + HALF];
+      const float tc = sI[r + HALF][x - x0 + HALF];
+      float a = 0.f;
+      for (int dy = 0; dy < BS; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < BS; ++dx) {
+          const int cw = min(x + dx - HALF, W - 1);                          // first clamp (x + dx - HALF >= 0 here)
+          const float e = sP[r + dy][cw - d - xp0 + HALF];
+          const float des = e - ec, dta = sI[r + dy][x - x0 + dx] - tc;
+          const float d2 = des * __builtin_amdgcn_rsqf(fmaf(des, des, eps)) - dta * __builtin_amdgcn_rsqf(fmaf(dta, dta, eps));
+          a = TYPE == 2 ? fmaf(d2, d2, a) : a + fabsf(d2);
+        }
+      cost[((long)f * D + d) * HW + (long)yy * W + x] = a * ((TYPE == 2 ? 0.25f : 0.5f) / (float)(BS * BS));
+    }
+  }
+}
+
+template <int BS>
+static int costvol_census_type(int type, const float* im, const float* pat, long pat_frame_stride, float* cost, int frames,
+                               int H, int W, int D, float eps, hipStream_t stream) {
+  const int n_chunks = ceil_div(D, kCcD);
+  const dim3 grid(ceil_div(W, kCcW), ceil_div(H, kCcR), frames * n_chunks);
+  if (grid.y > 65535 || (long)frames * n_chunks > 65535) return CTD_ERR_INVALID_ARG;
+  if (type == 2)
+    hipLaunchKernelGGL((costvol_census_kernel<2, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps);
+  else
+    hipLaunchKernelGGL((costvol_census_kernel<3, BS>), grid, dim3(256), 0, stream, im, pat, pat_frame_stride, cost, H, W, D, n_chunks, eps);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
 template <int BS>
 static int costvol_fast_type(int type, const float* im, const float* pat, long pat_frame_stride, float* cost, int frames,
                              int H, int W, int D, float eps, hipStream_t stream) {
@@ -729,6 +919,15 @@ static int costvol_fast_type(int type, const float* im, const float* pat, long p
 
 int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W,
                      int D, int bs, int type, float eps, hipStream_t stream) {
+  if (type >= 2) {                                   // census types: the census-transform kernel
+    switch (bs) {
+      case 3: return costvol_census_type<3>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+      case 5: return costvol_census_type<5>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+      case 7: return costvol_census_type<7>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+      case 9: return costvol_census_type<9>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
+      default: return CTD_ERR_UNSUPPORTED;
+    }
+  }
   if ((long)frames * ceil_div(D, kCvChunk) > 65535) return CTD_ERR_INVALID_ARG;
   switch (bs) {
     case 3: return costvol_fast_type<3>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);
