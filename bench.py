@@ -40,8 +40,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step (BASELINE config 2 / 3: 16)")
     ap.add_argument("--algo", default="fast", choices=["fast", "exact"])
-    ap.add_argument("--workload", default=None, choices=["config2", "config3"],
-                    help="default: config2 at one GPU, config3 (adds the geometric loss and its all-gather) at more")
+    ap.add_argument("--workload", default=None, choices=["config2", "config3", "config4"],
+                    help="default: config2 at one GPU, config3 (adds the geometric loss and its all-gather) at more; "
+                         "config4 = BASELINE configs[3]: 1024x1024 frames, 256 disparities, NCC volume + argmax and the "
+                         "soft-census cost volume (one frame per step unless --frames says otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps: no parity probe, no CPU baseline, no also_measured legs (what the profiling "
@@ -245,12 +247,146 @@ def also_measured(te, L, frames, pat_lcn, args):
     return {"volume_kernel_alone": plain, "fused_volume_free": fused}
 
 
+def run_config4(args):
+    """BASELINE configs[3], the HBM-bound stress: 1024x1024 frames, 256 disparities.  One step = LCN -> NCC volume
+    (materialised, 1 GiB per frame) + argmax with reference indices -> soft-census (census_sad, eps 0.5) cost volume of
+    the same frame by the census-transform kernel (another GiB).  `value` counts the pix*disp of BOTH volumes per step
+    time; `roofline` prices the NCC volume kernel at 4.03125 B per pix*disp, `census` the census kernel at 4 B + inputs."""
+    import ctypes
+    import numpy as np
+    import torch
+    H4, W4, D4 = 1024, 1024, 256
+    frames_n = args.frames if args.frames != 16 else 1
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    from connecting_the_dots_amd import _lib, torchext as te
+    from tests import workloads
+    L = _lib.lib()
+    fr = torch.from_numpy(np.stack([workloads.uniform_frame(1234 + i, H4, W4) for i in range(frames_n)])).to(device)
+    fr = fr.reshape(frames_n, 1, H4, W4).contiguous()
+    pat = torch.from_numpy(workloads.syn_dot_pattern(H4, W4, seed=42)).to(device).reshape(1, 1, H4, W4)
+    pat_lcn = te.lcn(pat.contiguous(), LCN_RADIUS, LCN_EPS)[0][0].contiguous()            # [1, H, W]
+    bpp = 4.0 + 8.0 / D4
+
+    def step():
+        x, _ = te.lcn(fr, LCN_RADIUS, LCN_EPS)
+        idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D4, BS, return_volume=True)
+        cen = te.costvol(x[:, 0], pat_lcn[0], D4, BS, "census_sad", 0.5, algo="fast")
+        return x, idx, vol, cen
+
+    import gc
+    gc.collect()
+    gc.disable()
+    L.ctd_kernel_timing_enable(2 * (args.steps + args.warmup) + 16)
+    t_settle, settle_steps = time.perf_counter(), 0
+    while time.perf_counter() - t_settle < 0.3 and settle_steps < 400:      # clocks (see the settle loop in main)
+        held = step()
+        settle_steps += 1
+        if settle_steps % 10 == 0:
+            torch.cuda.synchronize()
+            L.ctd_kernel_timing_collect(None, None)
+    for _ in range(args.warmup):
+        held = step()
+    torch.cuda.synchronize()
+    L.ctd_kernel_timing_collect(None, None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        held = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    L.ctd_kernel_timing_enable(0)
+    avg_ms, cols = ctypes.c_double(0), ctypes.c_int(0)
+    n_launch = L.ctd_kernel_timing_collect(ctypes.byref(avg_ms), ctypes.byref(cols))
+    x = held[0]
+    # the census kernel alone, device time (our kernels launch on torch's current stream, so torch events bracket them)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        te.costvol(x[:, 0], pat_lcn[0], D4, BS, "census_sad", 0.5, algo="fast")
+    e0.record()
+    for _ in range(args.steps):
+        cen = te.costvol(x[:, 0], pat_lcn[0], D4, BS, "census_sad", 0.5, algo="fast")
+    e1.record()
+    torch.cuda.synchronize()
+    cen_ms = e0.elapsed_time(e1) / args.steps
+    units = frames_n * H4 * W4 * D4
+    kernel_units = frames_n * H4 * cols.value * D4
+    achieved = kernel_units * bpp / (avg_ms.value * 1e-3) / 1e9 if n_launch else None
+    cen_bytes = units * 4.0 + frames_n * H4 * W4 * 8.0
+    out = {
+        "metric": "Mpix*disparities/s on 512x432x128 cost volume; disparity MAE vs ref",
+        "value": 2 * units * args.steps / elapsed / 1e6, "unit": "Mpix*disp/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "settle_steps": settle_steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4 (configs[3]): %d frame(s) of 1024x1024, 256 disparities, block 9: LCN + NCC "
+                               "cost volume (materialised) + argmax, then the soft-census (census_sad, eps 0.5) cost volume "
+                               "of the same frame; value counts both volumes" % frames_n,
+                   "frames_per_gpu": frames_n, "H": H4, "W": W4, "D": D4, "block_size": BS,
+                   "device": torch.cuda.get_device_name(device)},
+        "roofline": {"bound": "hbm", "kernel": "ncc_fast_alld_kernel (volume + ranking over every disparity in one workgroup)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "avg_launch_ms": avg_ms.value,
+                     "launches": n_launch, "algorithmic_bytes_per_launch": kernel_units * bpp, "traffic": None,
+                     "traffic_source": None},
+        "census": {"kernel": "costvol_census_kernel<3, 9> (census transform staged per tap, v_sad_u32 accumulation)",
+                   "avg_launch_ms": cen_ms, "value": units / (cen_ms * 1e-3) / 1e6, "unit": "Mpix*disp/s",
+                   "bound": "valu (81 v_sad_u32 per output) -- priced against the volume's bytes anyway",
+                   "achieved_GBs": cen_bytes / (cen_ms * 1e-3) / 1e9, "frac_of_hbm_peak": cen_bytes / (cen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_config4(pat_lcn.cpu(), x[0].cpu(), H4, W4, D4)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_config4(pat_lcn_cpu, frame_lcn_cpu, H4, W4, D4):
+    """The reference's CPU path on a bounded sample of config 4: (a) its xcorrvol_cpu on the full frame over the first
+    16 of the 256 disparities, (b) its photometric_loss_forward (census_sad) composed into the cost volume
+    over the first 8 disparities -- one core each (both loops are serial, ext_cpu.cpp:7-12)."""
+    import numpy as np
+    import torch
+    try:
+        from oracle import build_ref
+        ref = build_ref.load()
+    except Exception:
+        ref = None
+    torch.set_num_threads(1)
+    a, b = frame_lcn_cpu.contiguous(), pat_lcn_cpu.contiguous()         # [1, H, W]
+    dn, dc = 16, 8
+    t0 = time.perf_counter()
+    if ref is not None:
+        ref.xcorrvol_cpu(a, b, dn, BS)
+        kind = "reference"
+    else:
+        from oracle import oracle
+        oracle.xcorrvol(a.numpy(), b.numpy(), dn, BS, nthreads=1)
+        kind = "port"
+    t_ncc = time.perf_counter() - t0
+    cols = torch.arange(W4)
+    t0 = time.perf_counter()
+    for d in range(dc):
+        pd = b[:, :, (cols - d).clamp(0, W4 - 1)].reshape(1, 1, H4, W4).contiguous()
+        if ref is not None:
+            ref.photometric_loss_forward(pd, a.reshape(1, 1, H4, W4), BS, 3, 0.5)
+        else:
+            from oracle import oracle
+            oracle.photometric_fwd(pd.numpy(), a.reshape(1, 1, H4, W4).numpy(), BS, 3, 0.5)
+    t_cen = time.perf_counter() - t0
+    return {"value": H4 * W4 * dn / t_ncc / 1e6, "unit": "Mpix*disp/s", "cores": 1, "kind": kind,
+            "sample": "NCC: the full 1024x1024 frame over the first %d of %d disparities (xcorrvol_cpu), %.1f s" % (dn, D4, t_ncc),
+            "census": {"value": H4 * W4 * dc / t_cen / 1e6, "unit": "Mpix*disp/s", "cores": 1,
+                       "sample": "photometric_loss_forward(census_sad) on the pattern shifted by d = 0..%d, %.1f s" % (dc - 1, t_cen)}}
+
+
 def main():
     args = parse_args()
     if args.headline_only:
         args.no_parity_probe = args.no_cpu_baseline = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if args.workload == "config4":
+        if args.gpus != 1:
+            raise SystemExit("bench.py: --workload config4 is a one-GPU line")
+        return run_config4(args)
 
     import numpy as np
     import torch

@@ -720,7 +720,8 @@ __global__ __launch_bounds__(256) void costvol_fast_kernel(const float* __restri
 // so it is evaluated once per pattern column and tap, not once per output and tap (the v_rsq_f32 leaves the disparity
 // loop: 81 per PATTERN PIXEL instead of 81 per output, D = 128..256 times fewer), and likewise CI(y, x; dy, dx) once
 // per image pixel.  Per tap the workgroup stages CI for its 64 x 2 pixels and CP for the 64 + 127 pattern columns its
-// 128 disparities reach (2 evaluations per thread), then every thread accumulates its 4 pixels x 16 disparities:
+// 128 disparities reach (2 evaluations per thread and tap, three taps per barrier), then every thread accumulates its
+// 4 pixels x 16 disparities:
 //   census_sad: the values are staged as 24-bit FIXED POINT, u = round((t + 1) * 2^23) with t = des * rsq(des^2 + eps) in
 //     (-1, 1), and one v_sad_u32 per output and tap does |u_p - u_i| + acc (exact integer sum, 81 * 2^24 < 2^32; the
 //     rounding of a staged value is 2^-24, that of an f32 t 3e-8: the same accuracy);
@@ -730,6 +731,7 @@ __global__ __launch_bounds__(256) void costvol_fast_kernel(const float* __restri
 // Reference: torchext/ext/ext.h:244-259 (per-tap soft census), composition rule of SURVEY 8a/A6.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kCcW = 64, kCcR = 2, kCcD = 128, kCcDT = 16;   // pixel tile, disparities per workgroup / per thread
+constexpr int kCcTaps = 3;                                    // taps staged per barrier
 
 __device__ inline unsigned sad_u32(unsigned a, unsigned b, unsigned acc) {   // |a - b| + acc in one VALU instruction (no builtin)
   unsigned r;
@@ -748,8 +750,9 @@ __global__ __launch_bounds__(256) void costvol_census_kernel(const float* __rest
   typedef typename std::conditional<TYPE == 3, unsigned, float>::type cen_t;
   __shared__ float sI[TH][TW];
   __shared__ float sP[TH][SPW];
-  __shared__ __attribute__((aligned(16))) cen_t cI[2][kCcR][kCcW];
-  __shared__ __attribute__((aligned(16))) cen_t cP[2][kCcR][CPW];
+  constexpr int TS = kCcTaps;                       // taps staged per barrier
+  __shared__ __attribute__((aligned(16))) cen_t cI[2][TS][kCcR][kCcW];
+  __shared__ __attribute__((aligned(16))) cen_t cP[2][TS][kCcR][CPW];
   const int t = threadIdx.x;
   const int x0 = blockIdx.x * kCcW, y0 = blockIdx.y * kCcR;
   const int f = blockIdx.z / n_chunks, d0 = (blockIdx.z - f * n_chunks) * kCcD;
@@ -806,24 +809,33 @@ __global__ __launch_bounds__(256) void costvol_census_kernel(const float* __rest
     else return tt;
   };
   int buf = 0;
+  // taps in groups of TS per barrier (81 = 27 x 3 for block 9; a last partial group stages and accumulates fewer):
+  // one barrier per group -- a thread that writes buffer b for group n + 2 has passed the barrier of group n + 1, i.e.
+  // everybody finished reading group n
 #pragma unroll 1
-  for (int dy = 0; dy < BS; ++dy) {
-#pragma unroll 1
-    for (int dx = 0; dx < BS; ++dx) {
-      // stage this tap's census values (the buffer of the tap before last: every thread is past reading it, see below)
-      const float v0 = e0_img ? sI[e0r + dy][e0c + dx] : sP[e0r + dy][e0c + dx];
-      const float v1 = sP[e1r + dy][e1c + dx];
-      if (e0_img) cI[buf][e0r][e0c] = soft(v0 - c0);
-      else cP[buf][e0r][e0c] = soft(v0 - c0);
-      cP[buf][e1r][e1c] = soft(v1 - c1);
-      __syncthreads();                               // one barrier per tap: a thread that writes buffer b for tap n + 2 has
-                                                     // passed the barrier of tap n + 1, i.e. everybody finished reading tap n
+  for (int tap0 = 0; tap0 < BS * BS; tap0 += TS) {
+#pragma unroll
+    for (int u = 0; u < TS; ++u) {
+      const int tap = tap0 + u;
+      if (tap < BS * BS) {                           // (uniform)
+        const int dy = tap / BS, dx = tap - dy * BS;
+        const float v0 = e0_img ? sI[e0r + dy][e0c + dx] : sP[e0r + dy][e0c + dx];
+        const float v1 = sP[e1r + dy][e1c + dx];
+        if (e0_img) cI[buf][u][e0r][e0c] = soft(v0 - c0);
+        else cP[buf][u][e0r][e0c] = soft(v0 - c0);
+        cP[buf][u][e1r][e1c] = soft(v1 - c1);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TS; ++u) {
+      if (tap0 + u >= BS * BS) break;
       typedef cen_t c4 __attribute__((ext_vector_type(4)));
-      const c4 ci = *(const c4*)&cI[buf][row][4 * q];
+      const c4 ci = *(const c4*)&cI[buf][u][row][4 * q];
       cen_t cp[20];
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
-        const c4 w4 = *(const c4*)&cP[buf][row][jb + 4 * m];
+        const c4 w4 = *(const c4*)&cP[buf][u][row][jb + 4 * m];
         cp[4 * m] = w4[0]; cp[4 * m + 1] = w4[1]; cp[4 * m + 2] = w4[2]; cp[4 * m + 3] = w4[3];
       }
 #pragma unroll
@@ -837,8 +849,8 @@ __global__ __launch_bounds__(256) void costvol_census_kernel(const float* __rest
             acc[i][k] = fmaf(d2, d2, acc[i][k]);
           }
         }
-      buf ^= 1;
     }
+    buf ^= 1;
   }
   // 2 (h_p - h_i) = t_p - t_i: census_sad 0.5 / bs^2 (and 2^-23 for the fixed point), census_mse 0.25 / bs^2
   const float scale = TYPE == 3 ? 0.5f / (float)(BS * BS) / 8388608.f : 0.25f / (float)(BS * BS);
