@@ -14,6 +14,7 @@
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
 #include "ctd_rank.h"
+#include "ctd_tail.h"
 
 
 namespace ctd {
@@ -108,13 +109,21 @@ __device__ inline float wave_maxf(float v) {
 }
 
 // WORDS = 64-disparity words of the candidate mask (2 for D <= 128 ... 8 for D <= 512)
+// Fully clamped runs in a ranked call: the run spreading (runs_role) works beside this pass, so the volume's entries
+// past d_clamped are not read at all -- where the run's window is listed (zero reciprocal deviation in the pattern's
+// plane) the run's exact value comes from run_vals, elsewhere the copies equal the first element anyway.
+struct RunSource {
+  const float* run_vals;      // null: the volume is fully patched (unranked call), read it everywhere
+  const float* v1;
+  int W1, xoff, per_frame;
+};
+
 template <int WORDS, bool VOL>
-__global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __restrict__ vol,
-                                                             const float* __restrict__ in0,
-                                                             const float* __restrict__ in1, long in1_frame_stride,
-                                                             int64_t* __restrict__ idx, float* __restrict__ best,
-                                                             int D, int H, int W, int bs, float eps, WorkList work) {
-  extern __shared__ float lds_resolve[];
+__device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __restrict__ vol, const float* __restrict__ in0,
+                                             const float* __restrict__ in1, long in1_frame_stride,
+                                             int64_t* __restrict__ idx, float* __restrict__ best, int D, int H, int W, int bs,
+                                             float eps, WorkList work, RunSource rsrc, unsigned role_block,
+                                             unsigned n_role_blocks) {
   const int lane = threadIdx.x & 63;
   const int half = bs / 2, span = bs + D - 1;
   // per-wave staging area: frame window / pattern rows, raw and divided by bs^2 (the reference divides every tap
@@ -139,8 +148,8 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     longest = max(longest, seg_cnt[k]);
   }
   const unsigned n_slots = longest * (unsigned)work.parts;
-  const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-  for (unsigned slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < n_slots; slot += n_waves) {
+  const unsigned n_waves = n_role_blocks * (blockDim.x >> 6);
+  for (unsigned slot = role_block * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < n_slots; slot += n_waves) {
     const unsigned seg = slot & (unsigned)(work.parts - 1), entry = slot / (unsigned)work.parts;
     unsigned cnt = 0;
 #pragma unroll
@@ -154,9 +163,21 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     unsigned long long mask[WORDS];
     int n_cand = 0;
     float x[WORDS];
+    bool run_listed = false;                               // wave-uniform
+    float rv = 0.f;
     if constexpr (VOL) {
+      if (rsrc.run_vals && d_clamped < D) {
+        const long z = rsrc.per_frame ? fj : 0;              // (ranked calls are single channel)
+        run_listed = rsrc.v1[(z * H + hj) * rsrc.W1 + (rsrc.xoff - (bs - 1 - bs / 2))] == 0.f;
+        if (run_listed) rv = rsrc.run_vals[(fj * H + hj) * D + d_clamped];
+      }
 #pragma unroll
-      for (int wd = 0; wd < WORDS; ++wd) x[wd] = v[(long)min(wd * 64 + lane, D - 1) * HW];
+      for (int wd = 0; wd < WORDS; ++wd) {
+        const int d = min(wd * 64 + lane, D - 1);
+        // (a ranked call's run entries past d_clamped are being written by runs_role right now: not read)
+        x[wd] = v[(long)(rsrc.run_vals ? min(d, d_clamped) : d) * HW];
+        if (run_listed && d >= d_clamped) x[wd] = rv;
+      }
     }
     // !VOL (every pixel of the list is re-scored): the frame window and the pattern rows are requested at once, one
     // batch of independent loads per lane held in registers (block 9, D <= 128: kPreA + kPreB of them; -5 us of 0.53 ms).
@@ -284,10 +305,56 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
     if (lane == 0) {
       idx[pj] = ei;
       if (best) {
-        if constexpr (VOL) best[pj] = v[(long)ei * HW];
+        if constexpr (VOL) best[pj] = (run_listed && ei >= d_clamped) ? rv : v[(long)(rsrc.run_vals ? min(ei, d_clamped) : ei) * HW];
         else if (n_cand > 1) best[pj] = eb;                  // no fast score exists: the reference-order one
       }
     }
+  }
+}
+
+template <int WORDS, bool VOL>
+__global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __restrict__ vol, const float* __restrict__ in0,
+                                                             const float* __restrict__ in1, long in1_frame_stride,
+                                                             int64_t* __restrict__ idx, float* __restrict__ best, int D,
+                                                             int H, int W, int bs, float eps, WorkList work) {
+  extern __shared__ float lds_dyn[];
+  resolve_role<WORDS, VOL>(lds_dyn, vol, in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work,
+                           RunSource{nullptr, nullptr, 0, 0, 0}, blockIdx.x, gridDim.x);
+}
+
+// Tail of a ranked call, ONE launch behind the fix-up kernel, three independent roles by workgroup number:
+//   [0, n_resolve)            exact re-scoring of the work-list pixels (resolve_role);
+//   [.., + n_runs)            spreading of the listed fully clamped runs into the volume (runs_role; volume calls only);
+//   [.., + n_decode)          patched index words -> plain indices and best scores (decode_role).
+// All three need the fix-up kernel complete and nothing of each other: the resolve role reads run values from run_vals,
+// never from the part of the volume the runs role is writing, and the decode role leaves work-list pixels alone.
+// (As three kernels they were 36 + 24 us of dependent launches in round 2; each is a chain of global round trips with
+// most of the chip idle.)
+template <int WORDS, bool VOL>
+__global__ __launch_bounds__(256) void rank_tail_kernel(float* __restrict__ vol, const float* __restrict__ in0,
+                                                        const float* __restrict__ in1, long in1_frame_stride,
+                                                        int64_t* __restrict__ idx, float* __restrict__ best,
+                                                        const unsigned char* __restrict__ flags, int frames, int D, int H,
+                                                        int W, int bs, float eps, WorkList work, RunSource rsrc,
+                                                        const unsigned* __restrict__ counters,
+                                                        const unsigned long long* __restrict__ run_rows,
+                                                        const unsigned long long* __restrict__ flag_a,
+                                                        const unsigned long long* __restrict__ flag_b, unsigned n_resolve,
+                                                        unsigned n_runs, unsigned n_decode) {
+  extern __shared__ float lds_dyn[];
+  const unsigned b = blockIdx.x;
+  if (b < n_resolve) {
+    resolve_role<WORDS, VOL>(lds_dyn, vol, in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work, rsrc, b, n_resolve);
+  } else if (b < n_resolve + n_runs) {
+    if constexpr (VOL) {
+      const unsigned rb = b - n_resolve;
+      runs_role(vol, rsrc.run_vals, counters, run_rows, rsrc.per_frame, 1, H, W, D, bs, (int)(rb >> 2), (int)(rb & 3), 4,
+                (int*)lds_dyn);
+    }
+  } else {
+    const unsigned db = b - n_resolve - n_runs;
+    decode_role((unsigned long long*)idx, best, flags, counters, flag_a, flag_b, rsrc.per_frame, frames, H, W, D,
+                db * 4 + (threadIdx.x >> 6), n_decode * 4);
   }
 }
 
@@ -309,12 +376,34 @@ static int launch_resolve(const float* vol, const float* in0, const float* in1, 
   return CTD_OK;
 }
 
-int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
-                     int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
-  if (rp.eps < 0.f) return CTD_OK;                         // nothing is listed: plain argmax of the fast scores
+template <bool VOL>
+static int launch_tail(const RankPlan& rp, float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                       int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
+  size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
+  if (lds < sizeof(int) * (size_t)H) lds = sizeof(int) * (size_t)H;          // runs role: the rows of a frame's pattern
+  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
-  return vol ? launch_resolve<true>(vol, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.work, stream)
-             : launch_resolve<false>(nullptr, in0, in1, in1_frame_stride, idx, best, total, D, H, W, bs, rp.eps, rp.work, stream);
+  const long chunks = (total + 255) / 256;
+  const unsigned n_resolve = rp.eps >= 0.f ? (unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks) : 0u;
+  const unsigned n_runs = VOL ? (unsigned)(frames * ceil_div(D, kRunPlanes)) * 4u : 0u;
+  const unsigned n_decode = 128u;
+  auto kern = D <= 128 ? rank_tail_kernel<2, VOL> : (D <= 256 ? rank_tail_kernel<4, VOL> : rank_tail_kernel<8, VOL>);
+  if (lds > 64 * 1024)
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const RunSource rsrc = {rp.run_vals, rp.v1, rp.W1, rp.xoff, in1_frame_stride != 0 ? 1 : 0};
+  hipLaunchKernelGGL(kern, dim3(n_resolve + n_runs + n_decode), dim3(256), lds, stream, vol, in0, in1, in1_frame_stride, idx,
+                     best, rp.flags, frames, D, H, W, bs, rp.eps, rp.work, rsrc, rp.counters, rp.run_rows, rp.flag_a, rp.flag_b,
+                     n_resolve,
+                     n_runs, n_decode);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+// Last pass of a ranked call (after ncc_fast_fixup_ranked): see rank_tail_kernel.
+int rank_tail_f32(const RankPlan& rp, float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
+                  float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
+  return vol ? launch_tail<true>(rp, vol, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, bs, stream)
+             : launch_tail<false>(rp, nullptr, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, bs, stream);
 }
 
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,

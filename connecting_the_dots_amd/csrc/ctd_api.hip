@@ -205,7 +205,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
       if (st) return st;
       st = ncc_fast_fixup_ranked(in0, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, rp.best, hs);
       if (st) return st;
-      return rank_resolve_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, hs);
+      return rank_tail_f32(rp, vol_out, in0, in1, in1_frame_stride, idx, rp.best, frames, D, H, W, block_size, hs);
     }
     if (!vol_out) return CTD_ERR_INVALID_ARG;                              // this shape ranks a materialised volume
     int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,

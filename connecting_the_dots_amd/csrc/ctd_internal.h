@@ -30,6 +30,13 @@ struct RankPlan {
   WorkList work;              // work list of the pixels the exact re-scoring has to settle (counters cleared by the
                               // pre-pass kernel)
   float* best_scratch;        // [frames][H][W] best score when the caller does not ask for it
+  // what the tail kernel (runs | decode | resolve roles, argmax_rerank.hip) needs of the volume pass's workspace
+  const float* run_vals;      // [frames][H][D] exact values of the listed fully clamped runs
+  const unsigned long long* run_rows;
+  const unsigned* counters;   // [1] listed pattern windows, [2] listed run rows
+  const unsigned long long *flag_a, *flag_b;   // lists of the listed frame / pattern windows
+  const float* v1;            // pattern reciprocal-deviation planes (0 = listed window), row pitch W1, column x at x + xoff
+  int W1, xoff;
   size_t bytes;               // workspace bytes up to the end of these buffers
 };
 size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, bool per_frame_pattern);
@@ -45,8 +52,8 @@ int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_str
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
                       size_t workspace_bytes, bool counter_cleared, hipStream_t stream);
-int rank_resolve_f32(const RankPlan& rp, const float* vol, const float* in0, const float* in1, long in1_frame_stride,
-                     int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream);
+int rank_tail_f32(const RankPlan& rp, float* vol, const float* in0, const float* in1, long in1_frame_stride,
+                  int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream);
 
 // photometric.hip
 int photometric_fwd_f32(const float* es, const float* ta, float* out, int B, int C, int H, int W, int bs, int type,

@@ -32,6 +32,7 @@
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
 #include "ctd_rank.h"
+#include "ctd_tail.h"
 
 
 namespace ctd {
@@ -239,7 +240,7 @@ constexpr int kFixSpanRegs = 20;       // prefetched SPAN elements per lane (bs 
 template <int BS>
 __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0, const float* __restrict__ in1,
                                                 float* __restrict__ out, float* __restrict__ run_vals,
-                                                const float* __restrict__ best, const int64_t* __restrict__ idx,
+                                                const float* __restrict__ best, unsigned long long* __restrict__ idx,
                                                 float rank_eps,
                                                 unsigned* __restrict__ flags, WorkList work, float* sF, float* sFq,
                                                 float* sFv,
@@ -336,7 +337,7 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
         val[t] = 0.f;
         // the pixel's best score and index (ranked calls): requested now, needed after the exact evaluation
         mb[t] = (best && bad[t]) ? best[((long)f * H + h) * W + w] : 0.f;
-        won[t] = best && bad[t] && idx[((long)f * H + h) * W + w] == (int64_t)dd[t];   // the placeholder came out on top
+        won[t] = best && bad[t] && idx[((long)f * H + h) * W + w] == (unsigned long long)dd[t];   // the placeholder came out on top
       }
       const int o0 = min(dd[0], D - 1), o1 = min(dd[1], D - 1);    // clamped: lanes past D read valid LDS, results unused
       if (__any(bad[0] || bad[1])) {
@@ -383,7 +384,12 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
           if (out) out[((long)f * D + d) * HW + (long)h * W + w] = val[t];
         }
         if (best) {                                            // wave-uniform: ranked call
-          const bool contender = bad[t] && (won[t] || !(val[t] < mb[t] - rank_margin(rank_eps, mb[t])));
+          const long pixc = ((long)f * H + h) * W + w;
+          // clearly above everything the ranking saw: straight into the pixel's index word (ctd_tail.h); inside the
+          // margin of the best, or the placeholder itself came out on top with no such lead: exact re-scoring
+          const bool clear = bad[t] && val[t] > mb[t] + rank_margin(rank_eps, mb[t]);
+          if (clear) atomicMax(idx + pixc, patch_key(val[t], d));
+          const bool contender = bad[t] && !clear && (won[t] || !(val[t] < mb[t] - rank_margin(rank_eps, mb[t])));
           if (rounds == 1) {                                   // one slot per (frame of the item, t): flushed at the end
 #pragma unroll
             for (int i = 0; i < kCand; ++i)
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
                                                         const unsigned long long* __restrict__ list_b,
                                                         float* __restrict__ run_vals,
                                                         const float* __restrict__ best,
-                                                        const int64_t* __restrict__ idx, float rank_eps,
+                                                        unsigned long long* __restrict__ idx, float rank_eps,
                                                         unsigned* __restrict__ flags, WorkList work, int frames, int C, int H,
                                                         int W, int D, int bs_rt) {
   extern __shared__ float lds_fix[];
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
       const bool bad = d < D && w >= 0 && w < W;
       float val = 0.f;
       const float mbest = (best && bad) ? best[((long)f * H + h) * W + w] : 0.f;   // ranked calls: needed at the end
-      const bool won = best && bad && idx[((long)f * H + h) * W + w] == (int64_t)d;   // the placeholder came out on top
+      const bool won = best && bad && idx[((long)f * H + h) * W + w] == (unsigned long long)d;   // the placeholder came out on top
       if (__any(bad)) {
         for (int c = 0; c < C; ++c) {
           if (staged_c != c) {
@@ -546,92 +552,27 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
       if (best) {                                            // wave-uniform: ranked call
         bool take = false;
         const long pix = ((long)f * H + h) * W + w;
-        if (bad && (won || !(val < mbest - rank_margin(rank_eps, mbest)))) take = worklist_claim(flags, pix);
+        const bool clear = bad && val > mbest + rank_margin(rank_eps, mbest);      // (see the grouped path)
+        if (clear) atomicMax(idx + pix, patch_key(val, d));
+        if (bad && !clear && (won || !(val < mbest - rank_margin(rank_eps, mbest)))) take = worklist_claim(flags, pix);
         worklist_push(take, pix, work);
       }
     }
   }
 }
 
-// Second half of the run items: a workgroup per (frame, group of kRunPlanes disparity planes, quarter of the rows)
-// copies, for every listed fully clamped pattern window (row h, from `run_rows`), the run values of the pixels
-// w <= d - tail whose run has started (first disparity w + tail <= d) into the planes of its group -- (row, w) pairs
-// are flattened over the threads so that every thread has independent loads in flight.
-constexpr int kRunPlanes = 4;
-
+// Second half of the run items (ctd_tail.h: runs_role), as a kernel of its own for the unranked call; a ranked call runs
+// the same role inside its tail kernel (argmax_rerank.hip).
 __global__ __launch_bounds__(256) void ncc_fixup_runs_kernel(float* __restrict__ out, const float* __restrict__ run_vals,
                                                              const unsigned* __restrict__ counters,
                                                              const unsigned long long* __restrict__ run_rows, int per_frame,
                                                              int frames, int C, int H, int W, int D, int bs,
                                                              unsigned* __restrict__ rank_counter) {
   extern __shared__ int s_rows[];                          // up to C * H rows of this frame's pattern
-  __shared__ int s_n;
-  const int tid = threadIdx.x;
-  // a workgroup serves kRunPlanes consecutive disparity planes of one frame: the list scan and the loads of the run
-  // values (the same for every plane, only the run gets longer) are paid once for all of them -- the pass is a chain
-  // of dependent global round trips per workgroup, not bandwidth
-  const int n_pg = (D + kRunPlanes - 1) / kRunPlanes;
-  const int f = blockIdx.x / n_pg, d0 = (blockIdx.x - f * n_pg) * kRunPlanes;
-  const int d1 = min(d0 + kRunPlanes, D) - 1;              // last plane of the group
-  const int tail = bs - 1 - bs / 2;
-  const int seg_max = min(d1 - tail + 1, W);               // plane d: pixels w in [0, d - tail]
   // the work-list counter of the ranking pass that may follow (argmax_rerank.hip) lives at the start of the
   // workspace, which the volume kernel is done with by now: cleared here instead of by a memset of its own
-  if (rank_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *rank_counter = 0u;
-  const unsigned n_r = counters[2];
-  if (seg_max <= 0 || n_r == 0) return;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  for (unsigned j = tid; j < n_r; j += blockDim.x) {
-    const unsigned long long e = run_rows[j];
-    const int z = (int)(e >> 20), h = (int)(e & 0xFFFFF);
-    // rows are dealt to the gridDim.y workgroups of a plane group by h (late planes carry ~D pixels per row)
-    if ((!per_frame || z / C == f) && h % (int)gridDim.y == (int)blockIdx.y) s_rows[atomicAdd(&s_n, 1)] = h;
-  }
-  __syncthreads();
-  const long HW = (long)H * W;
-  // 32 lanes x 4 pixels span 128 pixels of a row, 8 rows per sweep of the workgroup: no index divisions, 16-byte
-  // accesses wherever the quad lies inside the run and the row starts are 16-byte aligned
-  const int wq = tid & 31, rs = tid >> 5;
-  const bool vec_ok = (D % 4 == 0) && (W % 4 == 0) && (tail % 4 == 0);
-  for (int w0 = 4 * wq; w0 < seg_max; w0 += 128) {
-    const bool full_max = vec_ok && w0 + 3 < seg_max;
-    for (int j0 = rs; j0 < s_n; j0 += 8 * 4) {
-      f32x4 v[4];
-      int hh[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 8 * u, s_n - 1);
-        hh[u] = s_rows[j];
-        const float* src = run_vals + ((long)f * H + hh[u]) * D + w0 + tail;
-        if (full_max) {
-          v[u] = *(const f32x4*)src;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[u][i] = w0 + i < seg_max ? src[i] : __int_as_float(0x7fc00000);
-        }
-      }
-      for (int d = d0; d <= d1; ++d) {
-        const int seg = min(d - tail + 1, W);
-        if (w0 >= seg) continue;
-        const bool full = vec_ok && w0 + 3 < seg;
-        float* plane = out + ((long)f * D + d) * HW;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (j0 + 8 * u >= s_n) continue;
-          float* dst = plane + (long)hh[u] * W + w0;
-          const bool all_set = v[u][0] == v[u][0] && v[u][1] == v[u][1] && v[u][2] == v[u][2] && v[u][3] == v[u][3];
-          if (full && all_set) {
-            *(f32x4*)dst = v[u];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (w0 + i < seg && v[u][i] == v[u][i]) dst[i] = v[u][i];
-          }
-        }
-      }
-    }
-  }
+  if (rank_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *rank_counter = 0u;
+  runs_role(out, run_vals, counters, run_rows, per_frame, C, H, W, D, bs, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, s_rows);
 }
 
 // 1 / (sa * sb + 1e-8) from the RECIPROCAL deviations the pre-pass stores: t = ra * rb, ONE multiply.  The reference's
@@ -2220,11 +2161,11 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(fix, dim3(kFixupBlocks), dim3(256), lds, stream, in0, in1, in1_frame_stride, out, ws.counters,
-                     ws.flag_a, ws.flag_b, ws.run_vals, rank ? best : nullptr, rank ? rank->idx : nullptr,
+                     ws.flag_a, ws.flag_b, ws.run_vals, rank ? best : nullptr, rank ? (unsigned long long*)rank->idx : nullptr,
                      rank ? rank->eps : -1.f,
                      rank ? (unsigned*)rank->flags : nullptr, rank ? rank->work : WorkList{}, frames, C, H, W, D, bs);
   CTD_LAUNCH_CHECK();
-  if (!out) return CTD_OK;                                   // nothing to spread without a volume
+  if (!out || rank) return CTD_OK;                           // nothing to spread without a volume; ranked calls spread in their tail kernel
   const size_t lds_rows = sizeof(int) * (size_t)C * H;
   if (lds_rows > 64 * 1024) return CTD_ERR_UNSUPPORTED;
   // (the old scan's work-list counter sits at the start of the workspace, which the volume kernel is done with by
@@ -2254,6 +2195,14 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
     rank->eps = in.eps;
     rank->idx = in.idx;
     rank->best = in.best ? in.best : rank->best_scratch;
+    rank->run_vals = ws.run_vals;
+    rank->run_rows = ws.run_rows;
+    rank->counters = ws.counters;
+    rank->flag_a = ws.flag_a;
+    rank->flag_b = ws.flag_b;
+    rank->v1 = ws.v1;
+    rank->W1 = ws.W1;
+    rank->xoff = ws.xoff;
     need = rank->bytes;
   }
   if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
