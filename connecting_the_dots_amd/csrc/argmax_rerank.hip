@@ -123,7 +123,10 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
                                              const float* __restrict__ in1, long in1_frame_stride,
                                              int64_t* __restrict__ idx, float* __restrict__ best, int D, int H, int W, int bs,
                                              float eps, WorkList work, RunSource rsrc, unsigned role_block,
-                                             unsigned n_role_blocks) {
+                                             unsigned n_role_blocks, unsigned waves_used = 4) {
+  // `waves_used` of the workgroup's four wavefronts work (the tail kernel uses two: half the staging LDS per workgroup,
+  // so that seven workgroups fit a CU instead of three and the other roles of that launch keep their concurrency)
+  if ((threadIdx.x >> 6) >= waves_used) return;
   const int lane = threadIdx.x & 63;
   const int half = bs / 2, span = bs + D - 1;
   // per-wave staging area: frame window / pattern rows, raw and divided by bs^2 (the reference divides every tap
@@ -148,8 +151,8 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
     longest = max(longest, seg_cnt[k]);
   }
   const unsigned n_slots = longest * (unsigned)work.parts;
-  const unsigned n_waves = n_role_blocks * (blockDim.x >> 6);
-  for (unsigned slot = role_block * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < n_slots; slot += n_waves) {
+  const unsigned n_waves = n_role_blocks * waves_used;
+  for (unsigned slot = role_block * waves_used + (threadIdx.x >> 6); slot < n_slots; slot += n_waves) {
     const unsigned seg = slot & (unsigned)(work.parts - 1), entry = slot / (unsigned)work.parts;
     unsigned cnt = 0;
 #pragma unroll
@@ -322,6 +325,9 @@ __global__ __launch_bounds__(256) void argmax_resolve_kernel(const float* __rest
                            RunSource{nullptr, nullptr, 0, 0, 0}, blockIdx.x, gridDim.x);
 }
 
+constexpr long kResolveBlocks = 1024;
+constexpr unsigned kTailResolveWaves = 2;       // working wavefronts of a resolve workgroup of the tail kernel
+
 // Tail of a ranked call, ONE launch behind the fix-up kernel, three independent roles by workgroup number:
 //   [0, n_resolve)            exact re-scoring of the work-list pixels (resolve_role);
 //   [.., + n_runs)            spreading of the listed fully clamped runs into the volume (runs_role; volume calls only);
@@ -342,23 +348,29 @@ __global__ __launch_bounds__(256) void rank_tail_kernel(float* __restrict__ vol,
                                                         const unsigned long long* __restrict__ flag_b, unsigned n_resolve,
                                                         unsigned n_runs, unsigned n_decode) {
   extern __shared__ float lds_dyn[];
-  const unsigned b = blockIdx.x;
-  if (b < n_resolve) {
-    resolve_role<WORDS, VOL>(lds_dyn, vol, in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work, rsrc, b, n_resolve);
-  } else if (b < n_resolve + n_runs) {
-    if constexpr (VOL) {
-      const unsigned rb = b - n_resolve;
+  // Roles by workgroup number, resolve and runs workgroups alternating while both last: the resolve role is the longest
+  // chain and must not queue behind the others for a CU slot, nor they behind it (all share one LDS size).
+  const unsigned n_pair = min(n_resolve, n_runs);
+  unsigned role, rb;                                          // 0 resolve, 1 runs, 2 decode; number within the role
+  if (blockIdx.x < n_decode) { role = 2; rb = blockIdx.x; }
+  else {
+    const unsigned b = blockIdx.x - n_decode;
+    if (b < 2 * n_pair) { role = b & 1; rb = b >> 1; }
+    else { role = n_resolve > n_runs ? 0 : 1; rb = b - n_pair; }
+  }
+  if (role == 0) {
+    resolve_role<WORDS, VOL>(lds_dyn, vol, in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work, rsrc, rb, n_resolve,
+                             kTailResolveWaves);
+  } else if (role == 1) {
+    if constexpr (VOL)
       runs_role(vol, rsrc.run_vals, counters, run_rows, rsrc.per_frame, 1, H, W, D, bs, (int)(rb >> 2), (int)(rb & 3), 4,
                 (int*)lds_dyn);
-    }
   } else {
-    const unsigned db = b - n_resolve - n_runs;
     decode_role((unsigned long long*)idx, best, flags, counters, flag_a, flag_b, rsrc.per_frame, frames, H, W, D,
-                db * 4 + (threadIdx.x >> 6), n_decode * 4);
+                rb * 4 + (threadIdx.x >> 6), n_decode * 4);
   }
 }
 
-constexpr long kResolveBlocks = 1024;
 
 template <bool VOL>
 static int launch_resolve(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
@@ -379,11 +391,13 @@ static int launch_resolve(const float* vol, const float* in0, const float* in1, 
 template <bool VOL>
 static int launch_tail(const RankPlan& rp, float* vol, const float* in0, const float* in1, long in1_frame_stride,
                        int64_t* idx, float* best, int frames, int D, int H, int W, int bs, hipStream_t stream) {
-  size_t lds = sizeof(float) * 4 * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
+  size_t lds = sizeof(float) * kTailResolveWaves * 2 * ((size_t)bs * bs + (size_t)bs * (bs + D - 1));
   if (lds < sizeof(int) * (size_t)H) lds = sizeof(int) * (size_t)H;          // runs role: the rows of a frame's pattern
   if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
   const long total = (long)frames * H * W;
   const long chunks = (total + 255) / 256;
+  // (only the pixels inside the margin come here, ctd_tail.h patch_key: a few thousand of millions; workgroups without
+  // an item leave at once)
   const unsigned n_resolve = rp.eps >= 0.f ? (unsigned)(chunks < kResolveBlocks ? chunks : kResolveBlocks) : 0u;
   const unsigned n_runs = VOL ? (unsigned)(frames * ceil_div(D, kRunPlanes)) * 4u : 0u;
   const unsigned n_decode = 128u;

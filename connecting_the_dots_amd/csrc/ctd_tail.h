@@ -26,7 +26,7 @@ __device__ inline unsigned long long patch_key(float val, int d) {
 // w <= d - tail whose run has started (first disparity w + tail <= d) into the planes of its group -- (row, w) pairs
 // are flattened over the threads so that every thread has independent loads in flight.
 // bx = frame * ceil(D / kRunPlanes) + plane group, by / gy = this workgroup's share of the rows; s_rows: >= C * H ints of LDS.
-constexpr int kRunPlanes = 4;
+constexpr int kRunPlanes = 8;
 
 __device__ inline void runs_role(float* __restrict__ out, const float* __restrict__ run_vals,
                                  const unsigned* __restrict__ counters, const unsigned long long* __restrict__ run_rows,

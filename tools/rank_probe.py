@@ -35,17 +35,4 @@ v = vol.masked_fill(dd > ww + 4, float("-inf"))
 t2 = v.topk(2, dim=1).values
 gap = (t2[:, 0] - t2[:, 1])
 print("pixels with fast gap < 1e-5:", int((gap < 1e-5).sum()), " < 1.4e-5:", int((gap < 1.4e-5).sum()))
-k0 = ws[off[0]:off[0] + 4 * N * off[4] * H * W].view(torch.float32).view(N, off[4], H, W)
-print("NaN keys:", int(torch.isnan(k0).sum()), " close flags:", int(((k0.view(torch.int32) & 16) != 0).sum()))
-# listed-window counters of the volume pass (FastWorkspace layout of ncc_fast.hip)
-def align(v, a): return (v + a - 1) // a * a
-Dpad = (D + 15) // 16 * 16
-xoff = Dpad + 3
-W1 = align(W + 4 + xoff, 4); Wp = align(W + 8, 4)
-n0 = align(N * H * Wp * 4, 256); n1 = align(H * W1 * 4, 256)
-cnt = ws[3 * n0 + 3 * n1: 3 * n0 + 3 * n1 + 16].view(torch.int32).cpu().tolist()
-print("listed frame windows %d, listed pattern windows %d (of which run rows %d)" % tuple(cnt[:3]))
-fl = ws[3 * n0 + 3 * n1 + 256 + align(N * H * W * 8, 256):][: 8 * cnt[1]].view(torch.int64).cpu().numpy()
-cols = (fl & 0xFFFFF) - 0x80000
-import collections
-print("listed pattern windows by column:", sorted(collections.Counter(cols.tolist()).items())[:14], "... max col", int(cols.max()))
+print("all-D kernel: %d rows per band, %d passes over the disparities" % (off[0], off[4]))
