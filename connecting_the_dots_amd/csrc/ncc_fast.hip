@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
       if (i0 + kSTW * kSRows * u < TRr * TCc) tile[i0 + kSTW * kSRows * u] = t[u];
   }
   __syncthreads();
-  const double n = (double)(bs * bs);
+  const double n = (double)(bs * bs), inv_n = 1.0 / n;
   const float cval = (float)(cred[0] / n);
   for (int r = ty; r < TRr; r += kSRows) {
     const float* row = tile + r * TCc + tx;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
         s1 += rs1[(r + k) * kSTW + tx];
         s2 += rs2[(r + k) * kSTW + tx];
       }
-    double mean = s1 / n;
+    double mean = s1 * inv_n;
     double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
     // Windows whose outputs the fast kernel cannot deliver within tolerance are listed for ncc_fixup_kernel
     // (see there), which recomputes EVERY output they take part in:
@@ -186,7 +186,11 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     const double mc = mean - (double)cval;
     const bool flat = 4e-8 * n * mean * mean > var || var < kDevFloor * kDevFloor;
     const bool listed = flat || n * mc * mc > kFlagRatio * var;
-    const float rdev = (float)(1.0 / sqrt(var > 0 ? var : 1.0));  // reciprocal deviation (see ncc_inv_norm)
+    // reciprocal deviation (see ncc_inv_norm): v_rsq_f32 and one Newton step in f32, 1e-7 relative -- the f64 square
+    // root and the two f64 divisions this line and `mean` used to cost were 60 % of the kernel's instructions
+    const float vf = (float)(var > 0 ? var : 1.0);
+    float rdev = __builtin_amdgcn_rsqf(vf);
+    rdev = fmaf(0.5f * rdev, fmaf(-vf * rdev, rdev, 1.f), rdev);
     const long o = ((long)img_idx * H + h) * W_out + xi;
     const int col = xi + x_start;
     out_mean[o] = (float)(jp.mean_scale * mc);
