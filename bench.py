@@ -579,11 +579,26 @@ def main():
         traffic, traffic_src = measured_traffic(kernel)
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_source"] = (traffic_src + " (rocprofv3 --pmc passes of this build, committed; not collected in this run)") if traffic_src else None
-        # second denominator: what a kernel that does nothing but this kernel's stores reaches on this card
-        ceil_tbs = committed_number("round3_store_ceiling_summary.txt", "all_d_pattern_store_only_TBs")
+        # second denominator: what a kernel that does NOTHING but this kernel's stores (same grid, same wave-instructions,
+        # same LDS-limited residency, non-temporal) reaches on THIS card, measured now by the microbenchmark
+        # tools/bin/ctd_store_ceiling (tools/ubench_src/store_ceiling.hip, built by __graft_entry__.build()); cards differ by
+        # more than 10 % here (profiles/round3_store_ceiling.txt), so a committed number would not do
+        ceil_tbs, ceil_src = None, None
+        exe = os.path.join(ROOT, "tools", "bin", "ctd_store_ceiling")
+        if workload == "config2" and world == 1 and os.path.exists(exe) and not args.headline_only:
+            try:
+                txt = subprocess.run([exe, "pattern"], capture_output=True, timeout=120).stdout.decode()
+                for line in txt.splitlines():
+                    if line.startswith("all_d_pattern_store_only_TBs"):
+                        ceil_tbs, ceil_src = float(line.split("=")[1]), "measured in this run (tools/bin/ctd_store_ceiling pattern)"
+            except Exception:                                  # noqa: BLE001
+                pass
+        if ceil_tbs is None:
+            ceil_tbs = committed_number("round3_store_ceiling_summary.txt", "all_d_pattern_store_only_TBs")
+            ceil_src = "profiles/round3_store_ceiling_summary.txt (another card: indicative only)" if ceil_tbs else None
         if ceil_tbs and achieved:
-            out["roofline"]["store_only_ceiling"] = {"GBs": ceil_tbs * 1e3, "frac_of_it": achieved / (ceil_tbs * 1e3),
-                                                     "source": "profiles/round3_store_ceiling_summary.txt (tools/ubench_src/store_ceiling.hip)"}
+            out["roofline"]["store_only_ceiling"] = {"GBs": ceil_tbs * 1e3, "frac_of_peak": ceil_tbs * 1e3 / HBM_PEAK_GBS,
+                                                     "kernel_frac_of_it": achieved / (ceil_tbs * 1e3), "source": ceil_src}
         if geo is not None and n_exchanged[0]:
             last = ring[(n_exchanged[0] - 1) % len(ring)]
             if last[1] is not None:

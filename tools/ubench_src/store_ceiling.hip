@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ i
 template <int POLICY>
 __global__ __launch_bounds__(1024) void volume_kernel(float* out, int H, int W, int D, int band_rows, int n_dg, int waves,
                                                       int all_d) {
+  extern __shared__ float lds_unused[];                  // (declared so that the launch's dynamic LDS size limits residency)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave >= waves) return;
   const int f = all_d ? blockIdx.z : blockIdx.z / n_dg;
@@ -107,6 +108,31 @@ __global__ __launch_bounds__(1024) void volume_kernel(float* out, int H, int W, 
       for (int j = 0; j < 2; ++j) {
         const int d = g * waves * 2 + wave * 2 + j;
         if (d < D) store16<POLICY>(out + (((long)f * D + d) * H + h) * W + col, v);
+      }
+}
+
+// all-D pattern with `burst` consecutive rows of a plane written back to back, optionally 512 columns per workgroup
+template <int POLICY>
+__global__ __launch_bounds__(1024) void burst_kernel(float* out, int H, int W, int D, int band_rows, int n_dg, int waves,
+                                                     int burst, int wide) {
+  extern __shared__ float lds_unused[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= waves) return;
+  const int f = blockIdx.z;
+  const int h_lo = blockIdx.y * band_rows, h_hi = min(h_lo + band_rows, H);
+  const int col = blockIdx.x * 256 + lane * 4;
+  const f32x4 v = {1.f, 2.f, 3.f, (float)wave};
+  for (int g = 0; g < n_dg; ++g)
+    for (int h0 = h_lo; h0 < h_hi; h0 += burst)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int d = g * waves * 2 + wave * 2 + j;
+        if (d >= D) continue;
+        for (int h = h0; h < min(h0 + burst, h_hi); ++h) {
+          float* p = out + (((long)f * D + d) * H + h) * W + col;
+          store16<POLICY>(p, v);
+          if (wide) store16<POLICY>(p + 256, v);
+        }
       }
 }
 
@@ -127,8 +153,35 @@ static void timeit(const char* pattern, const char* policy, unsigned grid, unsig
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int F = 16, D = 128, H = 432, W = 512;
+  if (argc > 1 && argv[1][0] == 'p') {
+    // `store_ceiling pattern`: only the all-D kernel's own pattern (13 storing wavefronts, 16 bands, one workgroup per CU,
+    // non-temporal), one `key = value` line -- what bench.py runs beside its timed region for the second denominator
+    const long n = (long)F * D * H * W;
+    float* o;
+    CK(hipMalloc(&o, n * 4));
+    CK(hipEventCreate(&ev_a));
+    CK(hipEventCreate(&ev_b));
+    CK(hipFuncSetAttribute((const void*)volume_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int waves = 13, bands = 16, n_dg = 5, band_rows = 27;
+    dim3 grid(W / 256, bands, F);
+    for (int i = 0; i < 400; ++i)
+      hipLaunchKernelGGL(volume_kernel<1>, grid, dim3(1024), (size_t)124 * 1024, 0, o, H, W, D, band_rows, n_dg, waves, 1);
+    float best_us = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(ev_a);
+      for (int i = 0; i < 20; ++i)
+        hipLaunchKernelGGL(volume_kernel<1>, grid, dim3(1024), (size_t)124 * 1024, 0, o, H, W, D, band_rows, n_dg, waves, 1);
+      hipEventRecord(ev_b);
+      hipEventSynchronize(ev_b);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev_a, ev_b);
+      if (ms * 50.f < best_us) best_us = ms * 50.f;
+    }
+    printf("all_d_pattern_store_only_us = %.1f\nall_d_pattern_store_only_TBs = %.3f\n", best_us, n * 4.0 / best_us / 1e6);
+    return 0;
+  }
   const long n_vol = (long)F * D * H * W;            // 1.81 GB: config 2's volume
   float *out, *in;
   CK(hipMalloc(&out, n_vol * 4));
@@ -186,20 +239,45 @@ int main() {
   timeit("copy16 (bytes = read + written)", "nt", 8192, 256, n_vol * 4.0, n_vol * 4.0,
          [&] { hipLaunchKernelGGL(copy16_kernel, dim3(8192), dim3(256), 0, 0, (const f32x4*)in, (f32x4*)out, n_vol / 8); });
   // 5. the volume kernel's own pattern
-  struct Cfg { int waves, bands, all_d; } cfgs[] = {{7, 10, 0}, {8, 10, 0}, {15, 16, 1}, {15, 8, 1}, {15, 24, 1},
-                                                    {14, 16, 1}, {16, 16, 1}, {7, 16, 1}};
+  // lds_kb > 0: dynamic LDS the workgroup declares (nothing is stored there): it limits the workgroups RESIDENT per CU the
+  // way the real kernels' staging does -- the per-group kernel holds 63 KB (two workgroups per CU), the all-D kernel
+  // 124 KB (one per CU, so its 512 workgroups run as two rounds of 256)
+  struct Cfg { int waves, bands, all_d, lds_kb; } cfgs[] = {{7, 10, 0, 0}, {7, 10, 0, 63}, {8, 10, 0, 0}, {15, 16, 1, 0},
+                                                            {13, 16, 1, 124}, {15, 16, 1, 124}, {15, 8, 1, 0}, {15, 8, 1, 124},
+                                                            {15, 24, 1, 0}, {14, 16, 1, 0}, {16, 16, 1, 0}, {7, 16, 1, 0}};
+  CK(hipFuncSetAttribute((const void*)volume_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)volume_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)volume_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)burst_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)burst_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   for (auto c : cfgs) {
     const int dg = c.waves * 2, n_dg = (D + dg - 1) / dg, band_rows = (H + c.bands - 1) / c.bands;
     dim3 grid(W / 256, (H + band_rows - 1) / band_rows, c.all_d ? F : F * n_dg);
     char name[96];
-    snprintf(name, sizeof name, "volume %2d waves %2d bands %s", c.waves, c.bands, c.all_d ? "all-D loop" : "per group");
+    snprintf(name, sizeof name, "volume %2d waves %2d bands %s LDS %3d KB", c.waves, c.bands, c.all_d ? "all-D" : "group", c.lds_kb);
     const unsigned block = c.waves <= 8 ? 512 : 1024;
+    const size_t lds = (size_t)c.lds_kb * 1024;
     POL(0, timeit(name, pname, grid.x * grid.y * grid.z, block, n_vol * 4.0, n_vol * 4.0, [&] {
-          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), 0, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
+          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), lds, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
     POL(1, timeit(name, pname, grid.x * grid.y * grid.z, block, n_vol * 4.0, n_vol * 4.0, [&] {
-          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), 0, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
+          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), lds, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
     POL(4, timeit(name, pname, grid.x * grid.y * grid.z, block, n_vol * 4.0, n_vol * 4.0, [&] {
-          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), 0, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
+          hipLaunchKernelGGL(volume_kernel<PP>, grid, dim3(block), lds, 0, out, H, W, D, band_rows, n_dg, c.waves, c.all_d); }));
   }
+  // 6. would a more sequential version of the all-D pattern pay?  burst = consecutive rows of one plane written back to
+  //    back by a wave (the kernel writes one row per plane and ~1 us); wide = the workgroup covers both 256-column tiles
+  //    (2 KB contiguous per plane row, written as two stores back to back)
+  for (int wide = 0; wide < 2; ++wide)
+    for (int burst : {1, 2, 4, 9}) {
+      const int waves = 13, bands = 16, dg = 26, n_dg = 5, band_rows = 27;
+      dim3 grid(wide ? 1 : W / 256, bands, F);
+      char name[96];
+      snprintf(name, sizeof name, "all-D 13 waves burst %d rows%s LDS 124", burst, wide ? ", 512 wide" : "");
+      (void)dg;
+      POL(1, timeit(name, pname, grid.x * grid.y * grid.z, 1024, n_vol * 4.0, n_vol * 4.0, [&] {
+            hipLaunchKernelGGL(burst_kernel<PP>, grid, dim3(1024), (size_t)124 * 1024, 0, out, H, W, D, band_rows, n_dg, waves, burst, wide); }));
+      POL(0, timeit(name, pname, grid.x * grid.y * grid.z, 1024, n_vol * 4.0, n_vol * 4.0, [&] {
+            hipLaunchKernelGGL(burst_kernel<PP>, grid, dim3(1024), (size_t)124 * 1024, 0, out, H, W, D, band_rows, n_dg, waves, burst, wide); }));
+    }
   return 0;
 }
