@@ -1,5 +1,5 @@
-"""GPU parity of the in-kernel ranking of the fast NCC path (ncc_fast.hip t256_consume -> rank_merge_kernel ->
-argmax_resolve_kernel): indices must equal torch.argmax of the reference-order volume bit for bit, with the volume
+"""GPU parity of the in-kernel ranking of the fast NCC path (ncc_fast.hip all-D kernel -> fix-up -> tail kernel):
+indices must equal torch.argmax of the reference-order volume bit for bit, with the volume
 materialised (return_volume=True) and without one (volume-free).  The checker is the reference-order HIP kernel
 (`algo='exact'`), itself pinned bit for bit to the reference's goldens in test_xcorrvol_gpu.py, and the CPU oracle
 for the small cases."""
@@ -36,7 +36,7 @@ def check_both_modes(te, A, B, D, what, exact=None):
     # the materialised volume is the plain fast volume (ranking must not disturb it)
     plain = te.xcorrvol_batch(A if A.dim() == 4 else A[None], B, D, 9, algo="fast")
     assert torch.equal(vol_v if vol_v.dim() == 4 else vol_v[None], plain), what
-    tol = vol_e.abs().amax(-3) * 1e-5 + 2e-6          # fast score + key truncation (2^-20 relative)
+    tol = vol_e.abs().amax(-3) * 1e-5 + 2e-6          # fast score + key resolution (2^-21 absolute)
     assert bool(((best_v - best_e).abs() <= tol).all()), what
     assert bool(((best_n - best_e).abs() <= tol).all()), what
     return idx_e
@@ -144,3 +144,26 @@ def test_rank_eps_negative_is_plain_fast_argmax(te):
     picked = vol.gather(1, idx[:, None])[:, 0]
     # scores of the clamped run are copies: compare values, not indices
     assert bool((vol.amax(1) - picked <= vol.amax(1).abs() * 4e-6 + 1e-7).all())
+
+
+def test_rank_eps_negative_with_listed_windows(te):
+    """rerank_eps < 0 on input with flat blocks and a listed fully clamped run (round-2 advice): the plain argmax must
+    be that of the returned (patched) volume -- scores of listed windows exist only there"""
+    rs = np.random.RandomState(31)
+    N, H, W, D = 2, 40, 96, 40
+    yy, xx = np.mgrid[0:H, 0:W]
+    bg = (100 + 60 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.float32)
+    a = (rs.rand(N, 1, H, W) * 8 + bg).astype(np.float32)
+    a[:, :, 5:22, 30:60] = 0.25
+    b = (rs.rand(1, H, W) * 20 + 0.6 * bg).astype(np.float32)
+    b[:, 10:30, 0:3] = 7.0
+    b[:, 24:38, 50:70] = 0.0
+    idx, best, vol = te.xcorrvol_argmax(dev(a), dev(b), D, 9, return_volume=True, algo="fast", rerank_eps=-1.0)
+    assert not bool(torch.isnan(vol).any())
+    assert int(idx.min()) >= 0 and int(idx.max()) < D
+    assert torch.equal(idx, vol.argmax(1)), int((idx != vol.argmax(1)).sum())
+    assert torch.equal(best, vol.amax(1))
+    # without a volume a negative eps means 0: exact re-scoring of what lies inside the key resolution -- reference indices
+    idx_n, _ = te.xcorrvol_argmax(dev(a), dev(b), D, 9, algo="fast", rerank_eps=-1.0)
+    idx_e = te.xcorrvol_argmax(dev(a), dev(b), D, 9, algo="exact")[0]
+    assert int((idx_n != idx_e).sum()) <= int(0.001 * idx_e.numel())        # (eps 0: no guarantee, nearly all agree)

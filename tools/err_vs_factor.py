@@ -1,6 +1,9 @@
 """Empirical error model of the fast NCC: err / (eps32 * sqrt(Fa*Fb)) where F = 1 + n*m'^2/var per window."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn.functional as F
+from connecting_the_dots_amd import _lib
+if os.environ.get('CTD_VARIANT'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['CTD_VARIANT'])
 from connecting_the_dots_amd import torchext as te
 from tests import workloads
 H, W, D = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
