@@ -1486,14 +1486,17 @@ constexpr int kASpanPad = (kAA + kADGMax - 1 + 1 + 3) / 4 * 4;   // 296: multipl
 static_assert(kAA + kADGMax - 1 < kASpanPad, "pattern span must fit its padded array");
 constexpr int kAHalo = kAWaves * 2 * 2 * 4;    // [wave][j][side][4] halo sums
 constexpr int kAPack = 3 * kAA + 3 * kASpanPad + kAHalo;   // 1920 floats per staged row
-constexpr int kARows = 3, kABufs = 3;
+constexpr int kABufs = 3;                     // LDS chunks in the ring; a chunk is ROWS = 3 or 2 staged rows (template parameter)
 constexpr int kADmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
 constexpr int kAOffB = 3 * kAA, kAOffH = 3 * kAA + 3 * kASpanPad;
-constexpr int kAMaxBandRows = 44;              // rank slots (2 KB per row) + staging ring <= 160 KB
+// band height limit: rank slots (2 KB per row) + staging ring <= 160 KB -- 44 rows with 3-row chunks, 57 with 2-row chunks
+constexpr int alld_max_band_rows(int rows) { return (160 * 1024 - (int)sizeof(float) * kABufs * rows * kAPack) / 2048; }
+constexpr int kAllowTwoRowChunks = 2;           // 3: never use 2-row chunks
+constexpr double kTwoRowPenalty = 1.03;
 constexpr int kTagBits = 9;                    // D <= 512
 constexpr unsigned kTagMask = (1u << kTagBits) - 1u;
 constexpr float kKeyBias = 6.f;
-static_assert((size_t)kAMaxBandRows * 2048 + sizeof(float) * kABufs * kARows * kAPack <= 160 * 1024, "LDS budget");
+static_assert(alld_max_band_rows(3) == 46 && alld_max_band_rows(2) == 57, "LDS budget");
 
 __device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {
   unsigned r;
@@ -1503,12 +1506,12 @@ __device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {
 // fixed-point units of the keys per unit of score, and the re-ranking margin in those units (ctd_rank.h: rank_margin)
 __device__ inline unsigned key_margin_units(float eps) { return (unsigned)ceilf(rank_margin(eps, 1.f) * 2097152.f); }
 
-template <bool STORE, int KS>
+template <bool STORE, int KS, int ROWS>
 __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, float* __restrict__ out, int WAVE, int f,
                                              int lane, int w_lo, int h_lo, int h_hi, int r_begin, int n_iters,
                                              int n_pass, int rot, int dgs, int H, int W, int D) {
-  constexpr int TAIL = 4, STEP = 6, CPI = STEP / kARows;          // block size 9
-  static_assert(STEP % kARows == 0, "a chunk never straddles two outer iterations");
+  constexpr int TAIL = 4, STEP = 6, CPI = STEP / ROWS;            // block size 9
+  static_assert(STEP % ROWS == 0, "a chunk never straddles two outer iterations");
   const long HW = (long)H * W;
   const unsigned l4 = 4u * (unsigned)lane;                         // first column of the lane, relative to w_lo
   float* vol = out + (long)f * D * HW + w_lo;
@@ -1566,9 +1569,9 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
 #pragma unroll
       for (int u = 0; u < STEP; ++u) {
         const int r = r_begin + it * STEP + u;
-        const bool last_of_chunk = (u % kARows) == kARows - 1;
+        const bool last_of_chunk = (u % ROWS) == ROWS - 1;
         // (addressing: one opaque per-row scalar plus one of two loop-invariant lane registers, see t256_consume)
-        int row_o = (slot * kARows + (u % kARows)) * kAPack + 4;
+        int row_o = (slot * ROWS + (u % ROWS)) * kAPack + 4;
         asm("" : "+s"(row_o));
         int own_o = row_o + (int)l4;
         asm("" : "+v"(own_o));
@@ -1586,7 +1589,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
         // The value quads of a chunk's first row are read here; those of its other rows were requested at the end of
         // the previous row, AHEAD of that row's returning atomics: LDS answers in order, and a read queued behind the
         // atomics would make phase A wait for their round trip.
-        if ((u % kARows) == 0) {
+        if ((u % ROWS) == 0) {
           qa = quad(own);
           qb0 = quad(pat);
           qb1 = quad(pat + 4);
@@ -1706,18 +1709,18 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
 }
 
 // MODE_STORE: the volume is materialised as well; otherwise nothing but indices / best scores / work list leave.
-template <bool STORE>
+template <bool STORE, int ROWS>
 __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
     float* __restrict__ out, int64_t* __restrict__ idx_out, float* __restrict__ best_out,
     unsigned char* __restrict__ flags_out, WorkList work, float rank_eps, int frames, int n_items, int H, int W, int D,
     int band_rows, int n_pass, int dgs, int Wp, int W1, int xoff) {
-  constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / kARows;
+  constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / ROWS;
   // [band_rows][top | second][256] rank slots first (their row base goes into one lane register), then the staging ring
   extern __shared__ float lds_all[];
   unsigned* rank_lds = (unsigned*)lds_all;
-  float* lds = lds_all + band_rows * 512;                          // [kABufs][kARows][kAPack]
+  float* lds = lds_all + band_rows * 512;                          // [kABufs][ROWS][kAPack]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Work item of this workgroup: column tile fastest, then band, then frame.  (XCD-aware orders -- every XCD a
   // contiguous range of the band-major list, so that co-resident workgroups share pattern rows in its L2 -- cut the
@@ -1735,7 +1738,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   const int r_begin = h_lo - HALF, r_end = h_hi - 1 + TAIL;
   const int n_rows = r_end - r_begin + 1;
   const int n_iters = (n_rows + STEP - 1) / STEP;
-  const int n_chunks = n_iters * CPI;                              // per pass; even
+  const int n_chunks = n_iters * CPI;                              // per pass; a multiple of CPI
   const int n_act = dgs / 2;                                       // consumer wavefronts with work
   const int rot = 0;                                               // first disparity group of this workgroup (pass p works on group (p + rot) % n_pass)
 
@@ -1759,13 +1762,13 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const int total = n_pass * n_chunks;                           // chunks of the whole workgroup, all passes
     int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;                 // the next chunk to issue: ring slot, pass, chunk in the pass
     auto issue_chunk = [&]() {
-      float* buf = lds + i_slot * (kARows * kAPack);
+      float* buf = lds + i_slot * (ROWS * kAPack);
       const int i_grp = i_pass + rot >= n_pass ? i_pass + rot - n_pass : i_pass + rot;
       const int xb = c_lo - (i_grp * dgs + dgs - 1);               // unclamped pattern column of span slot 0
       const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
 #pragma unroll
-      for (int s = 0; s < kARows; ++s) {
-        const int r = r_begin + i_ch * kARows + s;
+      for (int s = 0; s < ROWS; ++s) {
+        const int r = r_begin + i_ch * ROWS + s;
         const int rc = clampi(r, 0, H - 1);
         // statistics of output row r - TAIL; product rows that complete no output of the band re-read a row the band
         // needs anyway (no cache lines of their own)
@@ -1809,9 +1812,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     int h_slot = 0;                                                // ring slot of the next chunk to get its halo sums
     auto halo_chunk = [&](auto ub_tag) {
       constexpr int UB = decltype(ub_tag)::value;
-      const float* buf = lds + h_slot * (kARows * kAPack);
+      const float* buf = lds + h_slot * (ROWS * kAPack);
 #pragma unroll
-      for (int s = 0; s < kARows; ++s) {
+      for (int s = 0; s < ROWS; ++s) {
         const int u = (UB + s) % 6;
         const float* pk = buf + s * kAPack;
         float x[4];
@@ -1836,20 +1839,20 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
       }
       h_slot = h_slot == kABufs - 1 ? 0 : h_slot + 1;
     };
-    constexpr int L = kARows * kADmaPerRow;
+    constexpr int L = ROWS * kADmaPerRow;
     static_assert(L * (kABufs - 2) < 64, "in-flight DMA count must fit vmcnt");
-    static_assert(kABufs == 3 && CPI == 2, "the loop below spells out two chunks per iteration and a ring of three");
-    issue_chunk();                                                 // total >= 2 (n_chunks is even)
+    static_assert(kABufs == 3, "the loader runs two chunks ahead of the consumers");
+    issue_chunk();                                                 // total >= 2 (a pass has CPI >= 2 chunks)
     issue_chunk();
     wait_vmcnt<L>();                                               // chunk 0 has landed
     halo_chunk(std::integral_constant<int, 0>{});
     wait_lgkmcnt0();
     wg_barrier();
-    // chunk g of the flat sequence is chunk g % n_chunks of pass g / n_chunks: since n_chunks is even, the ring phase
-    // of a chunk's first row is 0 for even g and 3 for odd g, across pass boundaries too
-    for (int g = 0; g < total; g += 2) {
+    // chunk g of the flat sequence is chunk g % n_chunks of pass g / n_chunks; n_chunks is a multiple of CPI, so the
+    // ring phase of the first row of chunk g is (g % CPI) * ROWS, across pass boundaries too
+    for (int g = 0; g < total; g += CPI) {
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
+      for (int cc = 0; cc < CPI; ++cc) {
         if (i_n < total) {
           issue_chunk();
           wait_vmcnt<L>();                                         // chunk g + cc + 1 has landed
@@ -1857,8 +1860,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
           wait_vmcnt<0>();
         }
         if (g + cc + 1 < total) {
-          if (cc == 0) halo_chunk(std::integral_constant<int, 3>{});
-          else halo_chunk(std::integral_constant<int, 0>{});
+          if (cc == 0) halo_chunk(std::integral_constant<int, (1 % CPI) * ROWS>{});
+          else if (cc == 1) halo_chunk(std::integral_constant<int, (2 % CPI) * ROWS>{});
+          else halo_chunk(std::integral_constant<int, (3 % CPI) * ROWS>{});
         }
         wait_lgkmcnt0();
         wg_barrier();
@@ -1869,9 +1873,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
 
   // two copies of the consumer loop: the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * wave) % 4
   if ((dgs - 2 - 2 * wave) & 2)
-    alld_consume<STORE, 2>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
+    alld_consume<STORE, 2, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
   else
-    alld_consume<STORE, 0>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
+    alld_consume<STORE, 0, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
 
   // ---- emit: the band's final {top, second} -> index, best score, work-list flag.  The last chunk barrier (behind
   // every wavefront's lgkmcnt(0)) has made all slot updates visible.
@@ -2007,7 +2011,7 @@ static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, i
 // the band height.  One workgroup per CU is resident (LDS), every workgroup costs about (rows + 8 warm-up rows) x passes,
 // so the bands are chosen to minimise ceil(workgroups / 256) x (band rows rounded up to the 6-row unroll + 8).
 struct AlldPlan {
-  int n_pass, dgs, band_rows, bands;
+  int n_pass, dgs, band_rows, bands, chunk_rows;
   size_t lds;
 };
 static AlldPlan alld_plan(int frames, int H, int W, int D) {
@@ -2019,17 +2023,24 @@ static AlldPlan alld_plan(int frames, int H, int W, int D) {
   ap.n_pass = ceil_div(D, kADGMax);
   ap.dgs = 2 * ceil_div(ceil_div(D, 2), ap.n_pass);
   const long base = (long)ceil_div(W, 256) * frames;
-  long best_cost = -1;
-  ap.band_rows = H < kAMaxBandRows ? H : kAMaxBandRows;
-  for (int rows = kAMaxBandRows; rows >= 4; --rows) {
-    if (rows > H) continue;
-    const long wgs = base * ceil_div(H, rows);
-    const long cost = ((wgs + 255) / 256) * (long)(ceil_div(rows + 8, 6) * 6);
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; }
+  // Band height and chunk size: 3-row chunks allow bands of up to 46 rows, 2-row chunks (a third more chunk barriers,
+  // priced at kTwoRowPenalty) up to 57 -- config 2 is then ONE round of 256 workgroups of 54 rows (62 row steps per pass,
+  // 66 with the unroll) instead of two rounds of 27 (2 x 36).
+  double best_cost = -1;
+  ap.band_rows = H < 44 ? H : 44;
+  ap.chunk_rows = 3;
+  for (int cr = 3; cr >= kAllowTwoRowChunks; --cr) {
+    const int max_rows = alld_max_band_rows(cr) < 44 || cr == 2 ? alld_max_band_rows(cr) : 44;
+    for (int rows = max_rows; rows >= 4; --rows) {
+      if (rows > H) continue;
+      const long wgs = base * ceil_div(H, rows);
+      const double cost = (double)((wgs + 255) / 256) * (double)(ceil_div(rows + 8, 6) * 6) * (cr == 2 ? kTwoRowPenalty : 1.0);
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; ap.chunk_rows = cr; }
+    }
   }
   ap.bands = ceil_div(H, ap.band_rows);
   ap.band_rows = ceil_div(H, ap.bands);                          // the same number of bands, evenly tall
-  ap.lds = (size_t)ap.band_rows * 2048 + sizeof(float) * kABufs * kARows * kAPack;
+  ap.lds = (size_t)ap.band_rows * 2048 + sizeof(float) * kABufs * ap.chunk_rows * kAPack;
   return ap;
 }
 
@@ -2078,7 +2089,8 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     const AlldPlan ap = alld_plan(frames, H, W, D);
     const int n_items = ceil_div(W, 256) * ap.bands * frames;
     dim3 grid(n_items), block(64 * (kAWaves + 1));
-    auto kern = out ? ncc_fast_alld_kernel<true> : ncc_fast_alld_kernel<false>;
+    auto kern = ap.chunk_rows == 3 ? (out ? ncc_fast_alld_kernel<true, 3> : ncc_fast_alld_kernel<false, 3>)
+                                   : (out ? ncc_fast_alld_kernel<true, 2> : ncc_fast_alld_kernel<false, 2>);
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ap.lds));
     timing_begin(stream);
     hipLaunchKernelGGL(kern, grid, block, ap.lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
