@@ -197,7 +197,8 @@ __global__ __launch_bounds__(kTW* kTH, 3) void ncc_exact_kernel(
 // the pattern rows for ALL disparities staged in LDS with the replicate border baked in; a thread then walks the
 // disparities of its pixel with the taps coming from LDS (2 bs^2 LDS reads per output where the reference's kernel
 // makes 4 bs^2 global loads).  dot accumulates in the reference's order, multiply and add unfused.
-//   grid (ceil(W/64), ceil(H/4), frames), block (64, 4); LDS (4 + bs - 1) x ((64 + bs - 1) + (64 + bs - 1 + D - 1)) T
+//   grid (ceil(W/64), ceil(H/4), frames x disparity chunks), block (64, 4); LDS (4 + bs - 1) x ((64 + bs - 1) +
+//   (64 + bs - 1 + Dc - 1)) T for a chunk of Dc disparities (all of D when that fits 64 KB)
 // ---------------------------------------------------------------------------------
 template <typename T>
 struct Stat2 { T mu, sigma; };
@@ -205,15 +206,19 @@ struct Stat2 { T mu, sigma; };
 template <typename T>
 __global__ __launch_bounds__(kTW* kTH) void ncc_tiled_generic_kernel(
     const T* __restrict__ in0, const T* __restrict__ in1, long in1_frame_stride, const Stat2<T>* __restrict__ stats0,
-    const Stat2<T>* __restrict__ stats1, T* __restrict__ out, int C, int H, int W, int D, int bs) {
+    const Stat2<T>* __restrict__ stats1, T* __restrict__ out, int C, int H, int W, int D, int bs, int d_chunk,
+    int n_chunks) {
   extern __shared__ double smem_generic[];
   T* tile0 = (T*)smem_generic;
   const int half = bs / 2;
-  const int TR = kTH + bs - 1, TW0 = kTW + bs - 1, TW1 = kTW + bs - 1 + D - 1;
+  // blockIdx.z = frame * n_chunks + chunk: this workgroup serves the disparities [d_lo, d_hi) (the pattern rows of a
+  // chunk, not of all D, are what has to fit LDS)
+  const int f = blockIdx.z / n_chunks, d_lo = (blockIdx.z - f * n_chunks) * d_chunk, d_hi = min(d_lo + d_chunk, D);
+  const int TR = kTH + bs - 1, TW0 = kTW + bs - 1, TW1 = kTW + bs - 1 + (d_hi - d_lo) - 1;
   T* tile1 = tile0 + TR * TW0;
   const int W1 = W + D - 1;                    // stats1 row: x = w - d in [-(D-1), W-1]
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kTW + tx;
-  const int w_lo = blockIdx.x * kTW, h_lo = blockIdx.y * kTH, f = blockIdx.z;
+  const int w_lo = blockIdx.x * kTW, h_lo = blockIdx.y * kTH;
   const int w = w_lo + tx, h = h_lo + ty;
   const bool active = (w < W) && (h < H);
   const long HW = (long)H * W;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(kTW* kTH) void ncc_tiled_generic_kernel(
   const Stat2<T>* st0 = stats0 + (long)f * C * HW;
   const Stat2<T>* st1 = stats1 + (in1_frame_stride ? (long)f * C * H * W1 : 0);
   T* vol = out + (long)f * D * HW;
-  const int x0_tile1 = w_lo - half - (D - 1);
+  const int x0_tile1 = w_lo - half - (d_hi - 1);
   for (int c = 0; c < C; ++c) {
     __syncthreads();
     for (int i = tid; i < TR * TW0; i += kTW * kTH) {
@@ -237,10 +242,10 @@ __global__ __launch_bounds__(kTW* kTH) void ncc_tiled_generic_kernel(
     if (!active) continue;
     const Stat2<T> s0 = st0[(long)c * HW + (long)h * W + w];
     const Stat2<T>* st1x = st1 + ((long)c * H + h) * W1 + (D - 1) + w;       // st1x[-d] <-> x = w - d
-    for (int d = 0; d < D; ++d) {
+    for (int d = d_lo; d < d_hi; ++d) {
       const Stat2<T> s1 = st1x[-d];
       const T* r0 = tile0 + ty * TW0 + tx;
-      const T* r1 = tile1 + ty * TW1 + tx + (D - 1) - d;
+      const T* r1 = tile1 + ty * TW1 + tx + (d_hi - 1) - d;
       T dot = 0;
       for (int bh = 0; bh < bs; ++bh)
         for (int bw = 0; bw < bs; ++bw) {
@@ -270,8 +275,14 @@ static int launch_generic(const T* in0, const T* in1, long in1_frame_stride, T* 
   const bool per_frame = in1_frame_stride != 0;
   if (workspace == nullptr || workspace_bytes < generic_workspace_bytes<T>(frames, C, H, W, D, per_frame))
     return CTD_ERR_WORKSPACE;
-  const size_t lds = sizeof(T) * (size_t)(kTH + bs - 1) * ((kTW + bs - 1) + (kTW + bs - 1 + D - 1));
-  if (lds > 160 * 1024) return CTD_ERR_UNSUPPORTED;
+  // disparities per workgroup: as many as keep the two tiles within 64 KB of LDS (all of them for the usual shapes)
+  const size_t row = (size_t)(kTH + bs - 1) * sizeof(T);
+  const long fit = (long)(64 * 1024 / row) - 2 * (kTW + bs - 1) + 1;
+  if (fit < 1) return CTD_ERR_UNSUPPORTED;                       // (block sizes in the hundreds)
+  const int d_chunk = fit < D ? (int)fit : D;
+  const int n_chunks = ceil_div(D, d_chunk);
+  if ((long)frames * n_chunks > 65535) return CTD_ERR_UNSUPPORTED;
+  const size_t lds = row * ((kTW + bs - 1) + (kTW + bs - 1 + d_chunk - 1));
   Stat2<T>* stats0 = (Stat2<T>*)workspace;
   Stat2<T>* stats1 = (Stat2<T>*)((char*)workspace + align_up((size_t)frames * C * H * W * sizeof(Stat2<T>), 256));
   const int W1 = W + D - 1;
@@ -286,9 +297,10 @@ static int launch_generic(const T* in0, const T* in1, long in1_frame_stride, T* 
   auto kern = ncc_tiled_generic_kernel<T>;
   if (lds > 64 * 1024)
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), frames), block(kTW, kTH);
+  dim3 grid(ceil_div(W, kTW), ceil_div(H, kTH), frames * n_chunks), block(kTW, kTH);
   timing_begin(stream);
-  hipLaunchKernelGGL(kern, grid, block, lds, stream, in0, in1, in1_frame_stride, stats0, stats1, out, C, H, W, D, bs);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, in0, in1, in1_frame_stride, stats0, stats1, out, C, H, W, D, bs, d_chunk,
+                     n_chunks);
   timing_end(stream, W);
   CTD_LAUNCH_CHECK();
   return CTD_OK;

@@ -86,6 +86,21 @@ def test_xcorrvol_f64_vs_oracle(te, oracle):
     assert np.array_equal(vol, ref)
 
 
+def test_xcorrvol_generic_kernel_chunks_the_disparities(te, oracle):
+    """f64, block 15, D = 600: the pattern rows of all disparities (18 x 755 doubles = 109 KB beside the frame tile) do
+    not fit the generic kernel's 64 KB of LDS -- the disparities are served in chunks (round 2 returned
+    CTD_ERR_UNSUPPORTED from 160 KB on); two channels, so that the per-chunk channel accumulation is exercised too"""
+    rs = np.random.RandomState(15)
+    a, b = rs.rand(2, 9, 70), rs.rand(2, 9, 70)
+    ref = oracle.xcorrvol(a, b, 600, 15, nthreads=8)
+    vol = te.xcorrvol(dev(a), dev(b), 600, 15).cpu().numpy()
+    assert np.array_equal(vol, ref)
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)           # f32, even block: the same kernel
+    ref32 = oracle.xcorrvol(a32, b32, 1100, 12, nthreads=8)
+    vol32 = te.xcorrvol(dev(a32), dev(b32), 1100, 12, algo="exact").cpu().numpy()
+    assert np.array_equal(vol32, ref32)
+
+
 def test_xcorrvol_batch_shared_and_per_frame_pattern(te, oracle):
     rs = np.random.RandomState(8)
     a = rs.randn(3, 1, 20, 96).astype(np.float32)
