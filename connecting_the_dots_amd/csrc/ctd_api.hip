@@ -219,7 +219,8 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
 
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius, float eps, int device,
                 void* stream) {
-  if (N < 0 || H <= 0 || W <= 0 || radius < 0 || radius >= H || radius >= W) return CTD_ERR_INVALID_ARG;
+  if (N < 0 || H <= 0 || W <= 0 || radius < 0 || radius >= H || radius >= W || (double)H * W >= 2147483648.0)
+    return CTD_ERR_INVALID_ARG;
   if (N == 0) return CTD_OK;
   if (!x || !y || !std_out) return CTD_ERR_INVALID_ARG;
   DeviceGuard g(device);
