@@ -227,7 +227,7 @@ def also_measured(te, L, frames, pat_lcn, args):
     ms, cols = ctypes.c_double(0), ctypes.c_int(0)
     n = L.ctd_kernel_timing_collect(ctypes.byref(ms), ctypes.byref(cols))
     units = args.frames * H * cols.value * D
-    plain = {"kernel": "ncc_fast_t256_kernel (volume only, what ctd_xcorrvol_f32 launches)", "avg_launch_ms": ms.value, "launches": n,
+    plain = {"kernel": "ncc_fast_alld_kernel without the ranking (volume only, what ctd_xcorrvol_f32 launches)", "avg_launch_ms": ms.value, "launches": n,
              "achieved_GBs": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 if n else None,
              "frac_of_hbm_peak": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
     for _ in range(80):

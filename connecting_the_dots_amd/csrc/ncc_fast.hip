@@ -1491,6 +1491,7 @@ constexpr int kADmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 patte
 constexpr int kAOffB = 3 * kAA, kAOffH = 3 * kAA + 3 * kASpanPad;
 // band height limit: rank slots (2 KB per row) + staging ring <= 160 KB -- 44 rows with 3-row chunks, 57 with 2-row chunks
 constexpr int alld_max_band_rows(int rows) { return (160 * 1024 - (int)sizeof(float) * kABufs * rows * kAPack) / 2048; }
+constexpr int kAStore = 1, kARank = 2;          // MODE bits of the all-D kernel: materialise the volume / rank the scores
 constexpr int kAllowTwoRowChunks = 2;           // 3: never use 2-row chunks
 constexpr double kTwoRowPenalty = 1.03;
 constexpr int kTagBits = 9;                    // D <= 512
@@ -1506,11 +1507,12 @@ __device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {
 // fixed-point units of the keys per unit of score, and the re-ranking margin in those units (ctd_rank.h: rank_margin)
 __device__ inline unsigned key_margin_units(float eps) { return (unsigned)ceilf(rank_margin(eps, 1.f) * 2097152.f); }
 
-template <bool STORE, int KS, int ROWS>
+template <int MODE, int KS, int ROWS>
 __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, float* __restrict__ out, int WAVE, int f,
                                              int lane, int w_lo, int h_lo, int h_hi, int r_begin, int n_iters,
                                              int n_pass, int rot, int dgs, int H, int W, int D) {
   constexpr int TAIL = 4, STEP = 6, CPI = STEP / ROWS;            // block size 9
+  constexpr bool STORE = (MODE & kAStore) != 0, RANK = (MODE & kARank) != 0;
   static_assert(STEP % ROWS == 0, "a chunk never straddles two outer iterations");
   const long HW = (long)H * W;
   const unsigned l4 = 4u * (unsigned)lane;                         // first column of the lane, relative to w_lo
@@ -1611,7 +1613,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             T[j][i][u % 6] = t3;
           }
         // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
-        rank_second();
+        if constexpr (RANK) rank_second();
         auto prefetch_next = [&]() {                               // next row of the same chunk: one ring row further
           if (!last_of_chunk) {
             qa = quad(own + kAPack);
@@ -1655,7 +1657,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
               const float cov = fmaf(qma[i], me[kS + (1 - j) + i], sh);   // qma = -bs^2 * (window mean), from the pre-pass
               const float inv = ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
               if (STORE) val[i] = cov * inv;                        // the same bits as the plain volume kernels'
-              key[j][i] = (__float_as_uint(fmaf(cov, inv, kKeyBias)) << kTagBits) | (tag0 - (unsigned)j);
+              if constexpr (RANK) key[j][i] = (__float_as_uint(fmaf(cov, inv, kKeyBias)) << kTagBits) | (tag0 - (unsigned)j);
             }
             if (STORE && lane_out && d < D) {
               long ooff = (long)d * HW + (long)h * W;
@@ -1663,41 +1665,49 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
               // written once, next read by another kernel after 1.8 GB more: non-temporal
               __builtin_nontemporal_store(f32x4{val[0], val[1], val[2], val[3]}, (f32x4*)(vol + ooff + l4));
             }
-            if (d < D) {                                           // wave-uniform branch (a select would be 4 VALU slots)
-              if (run_masks) {                                     // wave-uniform: first column tile only
-                // d > w + TAIL: copy of the run's first element.  Loop-invariant compare: hoisted into a lane mask.
+            if constexpr (RANK) {
+              if (d < D) {                                         // wave-uniform branch (a select would be 4 VALU slots)
+                if (run_masks) {                                   // wave-uniform: first column tile only
+                  // d > w + TAIL: copy of the run's first element.  Loop-invariant compare: hoisted into a lane mask.
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  if (d - TAIL - i - w_lo > (int)l4) key[j][i] = 0u;
+                  for (int i = 0; i < 4; ++i)
+                    if (d - TAIL - i - w_lo > (int)l4) key[j][i] = 0u;
+                }
+              } else {
+                // (volatile: as plain assignments the compiler runs these four moves on EVERY row, ahead of the branch)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(key[j][i]));
               }
-            } else {
-              // (volatile: as plain assignments the compiler runs these four moves on EVERY row, ahead of the branch)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(key[j][i]));
             }
           }
           prefetch_next();
-          // slots of output row h: [row][top | second][column-in-quad][lane]
-          rk_sl = rank_lds + (it * STEP + u - 2 * TAIL) * 512 + lane;
+          if constexpr (RANK) {
+            // slots of output row h: [row][top | second][column-in-quad][lane]
+            rk_sl = rank_lds + (it * STEP + u - 2 * TAIL) * 512 + lane;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            rk_hi[i] = max(key[0][i], key[1][i]);
-            rk_lo[i] = min(key[0][i], key[1][i]);
-            rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 0; i < 4; ++i) {
+              rk_hi[i] = max(key[0][i], key[1][i]);
+              rk_lo[i] = min(key[0][i], key[1][i]);
+              rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         } else {
           prefetch_next();
-          // only the returned old top is reset: the next rank_second() then offers min(hi, lo) of the last output row
-          // once more -- a genuine non-top key of that pixel, harmless
+          if constexpr (RANK) {
+            // only the returned old top is reset: the next rank_second() then offers min(hi, lo) of the last output row
+            // once more -- a genuine non-top key of that pixel, harmless
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rk_old[i] = 0u;
+            for (int i = 0; i < 4; ++i) rk_old[i] = 0u;
+          }
         }
         if (last_of_chunk) {
           // the pass's last chunk has no next row to ride on: complete its slots before its barrier (wave-uniform)
-          if (it == n_iters - 1 && u == STEP - 1) {
-            rank_second();
+          if constexpr (RANK) {
+            if (it == n_iters - 1 && u == STEP - 1) {
+              rank_second();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = 0u;
+              for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = 0u;
+            }
           }
           wait_lgkmcnt0();
           wg_barrier();
@@ -1709,7 +1719,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
 }
 
 // MODE_STORE: the volume is materialised as well; otherwise nothing but indices / best scores / work list leave.
-template <bool STORE, int ROWS>
+template <int MODE, int ROWS>
 __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const float* __restrict__ ac, const float* __restrict__ m0, const float* __restrict__ v0,
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
@@ -1719,8 +1729,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / ROWS;
   // [band_rows][top | second][256] rank slots first (their row base goes into one lane register), then the staging ring
   extern __shared__ float lds_all[];
+  constexpr bool RANK = (MODE & kARank) != 0;
   unsigned* rank_lds = (unsigned*)lds_all;
-  float* lds = lds_all + band_rows * 512;                          // [kABufs][ROWS][kAPack]
+  float* lds = lds_all + (RANK ? band_rows * 512 : 0);             // [kABufs][ROWS][kAPack]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Work item of this workgroup: column tile fastest, then band, then frame.  (XCD-aware orders -- every XCD a
   // contiguous range of the band-major list, so that co-resident workgroups share pattern rows in its L2 -- cut the
@@ -1743,7 +1754,8 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   const int rot = 0;                                               // first disparity group of this workgroup (pass p works on group (p + rot) % n_pass)
 
   // every wavefront clears its share of the rank slots (key 0 = below every score)
-  for (int k = threadIdx.x; k < band_rows * 128; k += 64 * (kAWaves + 1)) ((uint4*)rank_lds)[k] = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (RANK)
+    for (int k = threadIdx.x; k < band_rows * 128; k += 64 * (kAWaves + 1)) ((uint4*)rank_lds)[k] = make_uint4(0u, 0u, 0u, 0u);
   wait_lgkmcnt0();                                                 // (the consumers' first barrier is a raw s_barrier)
 
   if (wave == kAWaves) {
@@ -1873,10 +1885,11 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
 
   // two copies of the consumer loop: the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * wave) % 4
   if ((dgs - 2 - 2 * wave) & 2)
-    alld_consume<STORE, 2, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
+    alld_consume<MODE, 2, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
   else
-    alld_consume<STORE, 0, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
+    alld_consume<MODE, 0, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
 
+  if constexpr (!RANK) return;                                     // plain volume call: nothing to emit
   // ---- emit: the band's final {top, second} -> index, best score, work-list flag.  The last chunk barrier (behind
   // every wavefront's lgkmcnt(0)) has made all slot updates visible.
   const unsigned l4 = 4u * (unsigned)lane;
@@ -2089,8 +2102,8 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     const AlldPlan ap = alld_plan(frames, H, W, D);
     const int n_items = ceil_div(W, 256) * ap.bands * frames;
     dim3 grid(n_items), block(64 * (kAWaves + 1));
-    auto kern = ap.chunk_rows == 3 ? (out ? ncc_fast_alld_kernel<true, 3> : ncc_fast_alld_kernel<false, 3>)
-                                   : (out ? ncc_fast_alld_kernel<true, 2> : ncc_fast_alld_kernel<false, 2>);
+    auto kern = ap.chunk_rows == 3 ? (out ? ncc_fast_alld_kernel<kAStore | kARank, 3> : ncc_fast_alld_kernel<kARank, 3>)
+                                   : (out ? ncc_fast_alld_kernel<kAStore | kARank, 2> : ncc_fast_alld_kernel<kARank, 2>);
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ap.lds));
     timing_begin(stream);
     hipLaunchKernelGGL(kern, grid, block, ap.lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
@@ -2101,8 +2114,24 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     CTD_LAUNCH_CHECK();
     return CTD_OK;
   }
+  if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0 && C == 1) {
+    // plain volume, single channel: the all-D kernel without the ranking (the same bits as with it)
+    const AlldPlan ap = alld_plan(frames, H, W, D);
+    const int n_items = ceil_div(W, 256) * ap.bands * frames;
+    const size_t lds = sizeof(float) * kABufs * ap.chunk_rows * kAPack;
+    dim3 grid(n_items), block(64 * (kAWaves + 1));
+    auto kern = ap.chunk_rows == 3 ? ncc_fast_alld_kernel<kAStore, 3> : ncc_fast_alld_kernel<kAStore, 2>;
+    CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    timing_begin(stream);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
+                       (int64_t*)nullptr, (float*)nullptr, (unsigned char*)nullptr, WorkList{}, -1.f, frames, n_items, H, W, D,
+                       ap.band_rows, ap.n_pass, ap.dgs, ws.Wp, ws.W1, ws.xoff);
+    timing_end(stream, W);
+    CTD_LAUNCH_CHECK();
+    return CTD_OK;
+  }
   if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0) {
-    // production path of the plain volume: 256-column tiles, every store a full aligned KB
+    // several channels (accumulating launches): 256-column tiles per disparity group, every store a full aligned KB
     const int n_dg = ceil_div(D, kTDG);
     const int n_tiles = ceil_div(W, kTTile);
     // Bands of ~44 rows (5.5x the (bs-1)-row warm-up).  Measured on config 2 (H = 432): 4 bands 0.448 ms, 8: 0.418,
