@@ -1,8 +1,9 @@
 #!/bin/bash
 # Collects the judged profile artefacts of one round into gpurun_out/profiles_<tag>/ (copy to profiles/ afterwards):
 #   <tag>_bench_kernel_stats.csv   per-kernel statistics of `python bench.py` from the rocprofv3 kernel trace, counting
-#                                   only each kernel's DOMINANT launch shape (the 16-frame launches of the timed steps;
-#                                   set-up launches such as the one-image LCN of the pattern have another grid)
+#                                   only each kernel's DOMINANT launch shape (set-up launches such as the one-image LCN
+#                                   of the pattern have another grid) and of those the last 20 = the timed steps (the
+#                                   settle loop before them runs on rising clocks; its average is kept in a column of its own)
 #   <tag>_pmc_hbm_traffic.json     FETCH_SIZE / WRITE_SIZE (KiB) per launch of the same launches, separate --pmc passes
 #   <tag>_bench_under_rocprof.json the bench line of the traced run
 # bench.py runs with --headline-only: the parity probe's 1-frame launches and the also_measured legs (plain volume
@@ -32,20 +33,24 @@ for r in csv.DictReader(open(trace)):
     grid = (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     per[short(r["Kernel_Name"])][grid].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = []
+STEPS = 20          # the timed region of the traced command: the LAST `--steps` launches of every kernel's dominant shape
 for k, grids in per.items():
-    grid, d = max(grids.items(), key=lambda kv: sum(kv[1]))
+    grid, d_all = max(grids.items(), key=lambda kv: sum(kv[1]))
+    d = d_all[-STEPS:]          # (trace rows are in dispatch order; the settle loop and warm-up before them run on rising clocks)
     n = len(d)
     mean = sum(d) / n
     sd = (sum((x - mean) ** 2 for x in d) / n) ** 0.5
     rows.append((sum(d), k, "x".join(grid), n, mean, min(d), max(d), sd, sum(len(v) for v in grids.values()) - n))
+    rows[-1] = rows[-1] + (sum(d_all) / len(d_all), len(d_all))
 rows.sort(reverse=True)
 total = sum(r[0] for r in rows)
 with open("%s/%s_bench_kernel_stats.csv" % (out, tag), "w") as f:
     w = csv.writer(f)
-    w.writerow(["Name", "Grid", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev", "CallsWithOtherGrids"])
-    for tot, k, grid, n, mean, lo, hi, sd, other in rows:
-        w.writerow([k, grid, n, tot, "%.1f" % mean, "%.2f" % (100.0 * tot / total), lo, hi, "%.1f" % sd, other])
-        print("%-60s grid %-16s calls %3d avg %9.1f us  (%d launches with other grids left out)" % (k[:60], grid, n, mean / 1e3, other))
+    w.writerow(["Name", "Grid", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev", "LaunchesLeftOut",
+                "AverageNsAllLaunchesOfTheRun", "AllLaunchesOfTheRun"])
+    for tot, k, grid, n, mean, lo, hi, sd, other, mean_all, n_all in rows:
+        w.writerow([k, grid, n, tot, "%.1f" % mean, "%.2f" % (100.0 * tot / total), lo, hi, "%.1f" % sd, other, "%.1f" % mean_all, n_all])
+        print("%-60s grid %-16s timed %3d avg %9.1f us  (all %d launches of the run: %.1f us)" % (k[:60], grid, n, mean / 1e3, n_all, mean_all / 1e3))
 
 # ---- HBM traffic of the same launch shapes
 dominant = {k: g for _, k, g, *_ in rows}
