@@ -93,3 +93,22 @@ def test_coordconv_grid():
     assert m.uv.shape == (1, 2, 5, 7)
     assert float(m.uv[0, 0, 0, 0]) == -1 and float(m.uv[0, 0, 0, -1]) == 1       # u spans [-1, 1] (modules.py:19)
     assert float(m.uv[0, 1, 0, 0]) == -1 and float(m.uv[0, 1, -1, 0]) == 1
+
+
+def test_all_d_plan_of_the_benchmark_shapes():
+    """Host logic of the ranked argmax (no GPU work): how the all-D kernel cuts the BASELINE shapes -- band height and
+    passes over the disparities (ctd_xcorrvol_rank_layout offsets[0] / [4]) -- and that its workspace query covers it."""
+    import ctypes
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    off = (ctypes.c_size_t * 5)()
+    assert L.ctd_xcorrvol_rank_layout(16, 432, 512, 128, 0, off) == 0
+    assert (off[0], off[4]) == (54, 5)             # config 2: one round of 256 workgroups, 5 passes of 26 disparities
+    assert L.ctd_xcorrvol_rank_layout(1, 1024, 1024, 256, 0, off) == 0
+    assert (off[0], off[4]) == (16, 9)             # config 4: 64 bands x 4 tiles = 256 workgroups, 9 passes
+    assert L.ctd_xcorrvol_rank_layout(1, 9, 4, 1, 0, off) == 0 and 1 <= off[0] <= 9 and off[4] == 1
+    assert L.ctd_xcorrvol_rank_supported(1, 432, 512, 128, 9) == 1
+    assert L.ctd_xcorrvol_rank_supported(1, 432, 510, 128, 9) == 0      # W % 4
+    assert L.ctd_xcorrvol_rank_supported(1, 432, 512, 600, 9) == 0      # D > 512
+    need = L.ctd_xcorrvol_argmax_workspace_bytes(16, 1, 432, 512, 128, 9, 1)
+    assert need >= L.ctd_xcorrvol_workspace_bytes(16, 1, 432, 512, 128, 9, 1) > 0
