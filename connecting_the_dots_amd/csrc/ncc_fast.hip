@@ -1128,14 +1128,14 @@ __global__ __launch_bounds__(64 * (kWWaves + 1)) void ncc_fast_wide_kernel(
 // sums into the staged row, one chunk ahead of the consumers and under the same barrier.
 // Volume stores that are not 128-byte aligned cost ~25 % of HBM write bandwidth
 // (tools/ubench_store.hip), and per-CU operand staging is limited to ~10 B/clk
-// (tools/ubench_struct.hip), hence 16 disparities per workgroup.
+// (tools/ubench_struct.hip), hence >= 12 disparities per workgroup (14: seven consumer wavefronts of two).
 // ------------------------------------------------------------------------------------
 constexpr int kTWaves = 7;                     // consumer wavefronts per workgroup.  7 (+ loader) = two 8-wave workgroups per CU at
                                                // 128 VGPRs = exactly 4 waves on every SIMD; with 6 two SIMDs carry 4 waves and two
                                                // carry 3, and the chunk barrier makes the lighter ones wait (measured: 7 is 9 % faster
                                                // although 10 groups of 14 disparities compute 140 for D = 128)
 constexpr int kTND = 2;                        // disparities per lane
-constexpr int kTDG = kTWaves * kTND;           // 16 disparities per workgroup
+constexpr int kTDG = kTWaves * kTND;           // 14 disparities per workgroup
 constexpr int kTTile = 256;                    // output columns per workgroup
 constexpr int kTA = kTTile + 8;                // frame-side array: 4 halo columns either side
 constexpr int kTSpanPad = (kTA + kTDG - 1 + 1 + 3) / 4 * 4;   // multiple of 4, > span
