@@ -27,6 +27,7 @@ SIGNATURES = {
     "ctd_kernel_timing_collect": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
     "ctd_xcorrvol_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_xcorrvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 7 + [_vp, _c_size_t, _c_int, _vp]),
+    "ctd_xcorrvol_pattern_prepare_f32": (_c_int, [_vp, _c_long] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_xcorrvol_f64": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_argmax_disp_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_int, _vp]),
     "ctd_xcorrvol_rank_supported": (_c_int, [_c_int] * 5),

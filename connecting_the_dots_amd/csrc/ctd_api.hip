@@ -117,9 +117,21 @@ size_t ctd_xcorrvol_workspace_bytes(int frames, int C, int H, int W, int D, int 
   return fast > exact ? fast : exact;
 }
 
+int ctd_xcorrvol_pattern_prepare_f32(const float* in1, long in1_frame_stride, int frames, int C, int H, int W, int D,
+                                     int block_size, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0 || frames == 0 || !in1) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return ncc_fast_prepare_pattern_f32(in1, in1_frame_stride, frames, C, H, W, D, block_size, workspace, workspace_bytes,
+                                      (hipStream_t)stream);
+}
+
 int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H,
                      int W, int D, int block_size, int algo, void* workspace, size_t workspace_bytes, int device,
                      void* stream) {
+  const bool prepared = (algo & CTD_PATTERN_PREPARED) != 0;
+  algo &= ~CTD_PATTERN_PREPARED;
+  if (prepared && algo != CTD_NCC_FAST) return CTD_ERR_INVALID_ARG;
   if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
   if (frames == 0) return CTD_OK;
   if (!in0 || !in1 || !out) return CTD_ERR_INVALID_ARG;
@@ -130,7 +142,7 @@ int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, 
                          (hipStream_t)stream);
   if (algo == CTD_NCC_FAST)
     return ncc_fast_f32(in0, in1, in1_frame_stride, out, frames, C, H, W, D, block_size, workspace, workspace_bytes,
-                        nullptr, (hipStream_t)stream);
+                        nullptr, prepared, (hipStream_t)stream);
   return CTD_ERR_INVALID_ARG;
 }
 
@@ -178,6 +190,9 @@ size_t ctd_xcorrvol_argmax_workspace_bytes(int frames, int C, int H, int W, int 
 int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx,
                             float* best, int frames, int C, int H, int W, int D, int block_size, int algo,
                             float rerank_eps, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  const bool prepared = (algo & CTD_PATTERN_PREPARED) != 0;
+  algo &= ~CTD_PATTERN_PREPARED;
+  if (prepared && algo != CTD_NCC_FAST) return CTD_ERR_INVALID_ARG;
   if (!vol_shape_ok(frames, C, H, W, D, block_size) || in1_frame_stride < 0) return CTD_ERR_INVALID_ARG;
   if (C != 1) return CTD_ERR_UNSUPPORTED;
   if (frames == 0) return CTD_OK;
@@ -201,7 +216,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
       rp.best = best;
       const hipStream_t hs = (hipStream_t)stream;
       int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
-                            workspace_bytes, &rp, hs);                 // pre-pass + all-D kernel
+                            workspace_bytes, &rp, prepared, hs);       // pre-pass + all-D kernel
       if (st) return st;
       st = ncc_fast_fixup_ranked(in0, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, rp.best, hs);
       if (st) return st;
@@ -209,7 +224,7 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
     }
     if (!vol_out) return CTD_ERR_INVALID_ARG;                              // this shape ranks a materialised volume
     int st = ncc_fast_f32(in0, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace,
-                          workspace_bytes, nullptr, (hipStream_t)stream);
+                          workspace_bytes, nullptr, prepared, (hipStream_t)stream);
     if (st) return st;
     return argmax_rerank_f32(vol_out, in0, in1, in1_frame_stride, idx, best, frames, D, H, W, block_size, rerank_eps,
                              workspace, workspace_bytes, /*counter_cleared=*/true, (hipStream_t)stream);

@@ -44,7 +44,10 @@ bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs);
 size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern);
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off);
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
-                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream);
+                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, bool pattern_prepared,
+                 hipStream_t stream);
+int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int frames, int C, int H, int W, int D, int bs,
+                                 void* workspace, size_t workspace_bytes, hipStream_t stream);
 int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,
                           int D, int bs, void* workspace, const RankPlan& rank, const float* best, hipStream_t stream);
 

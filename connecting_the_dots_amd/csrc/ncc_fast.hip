@@ -2075,7 +2075,7 @@ static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
   size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
-  const int w_out = ja.W_out > jb.W_out ? ja.W_out : jb.W_out;
+  const int w_out = jb.nimg == 0 ? ja.W_out : (ja.nimg == 0 || jb.W_out > ja.W_out ? jb.W_out : ja.W_out);
   dim3 grid(ceil_div(w_out, kSTW), ceil_div(H, kSTH), ja.nimg + jb.nimg), block(kSTW, kSRows);
   hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, ja, jb, H, W, bs,
                      work ? work->counters : nullptr, work ? work->parts : 0);
@@ -2225,8 +2225,28 @@ static int launch_fixup(const float* in0, const float* in1, long in1_frame_strid
 // nothing is materialised then), ranks every pixel's scores in LDS and writes idx / best / work-list flags itself;
 // *rank comes back filled with the buffers the later passes need and the call STOPS after that kernel -- the caller
 // runs ncc_fast_fixup_ranked (which needs the best scores and indices), then rank_resolve_f32.
+// Pattern half of the pre-pass alone (ctd_xcorrvol_pattern_prepare_f32): the pattern's planes, its list of listed windows
+// and run rows stay in `workspace`; calls with `pattern_prepared` on the SAME workspace and shape then skip that half (the
+// reference prepares the pattern once per run, model/exp_synph.py:64-71).  The layout depends on `frames`.
+int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int frames, int C, int H, int W, int D, int bs,
+                                 void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
+  if (H >= (1 << 20) || W + D >= (1 << 19) || D > 512 || (long)frames * C >= (1 << 24)) return CTD_ERR_UNSUPPORTED;
+  const bool per_frame = in1_frame_stride != 0;
+  if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
+  FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
+  if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
+  CTD_HIP_TRY(hipMemsetAsync(ws.counters + 1, 0, 8, stream));
+  const PrepassJob ja = {in1, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, 0, ws.counters, ws.flag_a, 0, W,
+                         nullptr, nullptr, -(double)(bs * bs)};                       // (no frame images in this launch)
+  const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0};
+  return launch_prepass(ja, jb, H, W, bs, nullptr, stream);
+}
+
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
-                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, hipStream_t stream) {
+                 int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, bool pattern_prepared,
+                 hipStream_t stream) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
   if (H >= (1 << 20) || W + D >= (1 << 19) || D > 512 || (long)frames * C >= (1 << 24)) return CTD_ERR_UNSUPPORTED;
   if (!out && !rank) return CTD_ERR_INVALID_ARG;
@@ -2252,14 +2272,17 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   }
   if (workspace == nullptr || workspace_bytes < need) return CTD_ERR_WORKSPACE;
   if (rank && !rank->idx) return CTD_ERR_INVALID_ARG;
-  CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
+  // counters: [0] listed frame windows, [1] listed pattern windows, [2] listed run rows -- the last two belong to the
+  // pattern and survive when it was prepared
+  CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, pattern_prepared ? 4 : 16, stream));
   // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
                          nullptr, nullptr, -(double)(bs * bs)};
-  const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0};
+  const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1,
+                         pattern_prepared ? 0 : (per_frame ? frames : 1) * C, ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W,
+                         ws.counters + 2, ws.run_rows, 1.0};
   int st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
   if (st) return st;
   switch (bs) {

@@ -233,10 +233,40 @@ def argmax_disp(vol):
     return (idx[0], best[0]) if squeeze else (idx, best)
 
 
-def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=None, rerank_eps=1e-5):
+class PreparedPattern:
+    """The pattern half of the fast NCC path, done once (`prepare_pattern`): holds the workspace the pattern's window
+    statistics and fix-up lists live in -- dedicated to the calls that pass this object -- and the shape it is valid for."""
+
+    def __init__(self, in1, n_frames, n_disps, block_size, workspace):
+        self.in1, self.n_frames, self.n_disps, self.block_size, self.workspace = in1, n_frames, n_disps, block_size, workspace
+
+
+def prepare_pattern(in1, n_frames, n_disps, block_size):
+    """Additive: window statistics / fix-up lists of the pattern `in1` ([1,H,W] shared, or [N,1,H,W] per frame), computed
+    ONCE for all later `xcorrvol_argmax(..., prepared=handle)` calls with `n_frames` frames of the same shape -- the
+    reference prepares its pattern once per run too (model/exp_synph.py:64-71).  Fast path, C == 1."""
+    _check(in1, "in1", (torch.float32,))
+    if in1.dim() not in (3, 4) or in1.shape[-3] != 1:
+        raise RuntimeError("prepare_pattern expects in1 [1,H,W] or [N,1,H,W]")
+    H, W = in1.shape[-2:]
+    D, bs, N = int(n_disps), int(block_size), int(n_frames)
+    if not _ncc_fast_covers(in1.dtype, D, bs):
+        raise RuntimeError("prepare_pattern: the fast NCC path does not cover this block size / disparity range")
+    L = _lib.lib()
+    dev = in1.device
+    ws = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, 1, H, W, D, bs, 1), dev)
+    stride1 = 0 if in1.dim() == 3 else H * W
+    st = L.ctd_xcorrvol_pattern_prepare_f32(_ptr(in1), stride1, N, 1, H, W, D, bs, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(st, "prepare_pattern")
+    return PreparedPattern(in1, N, D, bs, ws)
+
+
+def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=None, rerank_eps=1e-5, prepared=None):
     """Additive: fused NCC volume + argmax over disparity (C == 1).
     in0 [N,1,H,W] | [1,H,W]; in1 [1,H,W] | [N,1,H,W].
-    Returns (idx int64, best f32[, volume]); idx == torch.argmax(xcorrvol(...), 0) of the reference."""
+    Returns (idx int64, best f32[, volume]); idx == torch.argmax(xcorrvol(...), 0) of the reference.
+    `prepared`: a `prepare_pattern` handle of the same `in1`, frame count and shape (fast path only): the pattern half of
+    the pre-pass is skipped and the handle's workspace is used."""
     _check(in0, "in0", (torch.float32,))
     _check(in1, "in1", (torch.float32,))
     squeeze = in0.dim() == 3
@@ -261,9 +291,16 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
     # the fast path ranks inside the volume kernel where it can (no volume needed); other shapes rank a materialised one
     need_vol = a == 1 and not L.ctd_xcorrvol_rank_supported(C, H, W, D, bs)
     vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if (return_volume or need_vol) else None
-    ws = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, bs, a), dev)
+    if prepared is not None:
+        if (a != 1 or prepared.in1 is not in1 or prepared.n_frames != N or prepared.n_disps != D or prepared.block_size != bs
+                or prepared.workspace.device != dev):
+            raise RuntimeError("xcorrvol_argmax: `prepared` belongs to another pattern, frame count, shape or device "
+                               "(or algo is not 'fast')")
+        ws, a_flag = prepared.workspace, a | 0x100                   # CTD_PATTERN_PREPARED
+    else:
+        ws, a_flag = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, bs, a), dev), a
     st = L.ctd_xcorrvol_argmax_f32(_ptr(a0), _ptr(in1), stride1, _ptr(vol), _ptr(idx), _ptr(best), N, C, H, W, D, bs,
-                                   a, float(rerank_eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+                                   a_flag, float(rerank_eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
     _lib.check(st, "xcorrvol_argmax")
     if squeeze:
         idx, best = idx[0], best[0]

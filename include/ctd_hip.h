@@ -87,6 +87,17 @@ int ctd_xcorrvol_f32(const float* in0, const float* in1, long in1_frame_stride, 
                      int frames, int C, int H, int W, int D, int block_size, int algo,
                      void* workspace, size_t workspace_bytes, int device, void* stream);
 
+/* Pattern half of the fast path's pre-pass, ONCE per pattern: the reference prepares the pattern once per run
+ * (model/exp_synph.py:64-71: LCN of the pattern in the Worker's constructor), its xcorrvol op re-reads it on every call.
+ * Writes the pattern's window statistics, its list of windows for the fix-up pass and run rows into `workspace`
+ * (ctd_xcorrvol_argmax_workspace_bytes() for the same frames / shape: the layout depends on all of them).  Afterwards
+ * ctd_xcorrvol_f32 / ctd_xcorrvol_argmax_f32 calls with algo = CTD_NCC_FAST | CTD_PATTERN_PREPARED, the SAME workspace,
+ * in1, in1_frame_stride, frames and shape skip that half.  The caller keeps the workspace to these calls in between. */
+#define CTD_PATTERN_PREPARED 0x100
+int ctd_xcorrvol_pattern_prepare_f32(const float* in1, long in1_frame_stride, int frames, int C, int H,
+                                     int W, int D, int block_size, void* workspace,
+                                     size_t workspace_bytes, int device, void* stream);
+
 int ctd_xcorrvol_f64(const double* in0, const double* in1, long in1_frame_stride, double* out,
                      int frames, int C, int H, int W, int D, int block_size,
                      void* workspace, size_t workspace_bytes, int device, void* stream);

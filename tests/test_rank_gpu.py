@@ -167,3 +167,30 @@ def test_rank_eps_negative_with_listed_windows(te):
     idx_n, _ = te.xcorrvol_argmax(dev(a), dev(b), D, 9, algo="fast", rerank_eps=-1.0)
     idx_e = te.xcorrvol_argmax(dev(a), dev(b), D, 9, algo="exact")[0]
     assert int((idx_n != idx_e).sum()) <= int(0.001 * idx_e.numel())        # (eps 0: no guarantee, nearly all agree)
+
+
+def test_prepared_pattern_gives_the_same_results(te):
+    """prepare_pattern once, then several calls: index, best score and volume bit-identical to the unprepared call -- on
+    the LCN'd dot pattern (listed clamped runs: the fix-up lists of the pattern must survive between calls), with and
+    without a volume, shared and per-frame patterns"""
+    H, W, D = 60, 512, 128
+    fr = np.stack([workloads.uniform_frame(1234 + i, H, W) for i in range(3)])
+    pat = workloads.syn_dot_pattern(H, W, seed=42)[None, None]
+    x, _ = te.lcn(dev(fr), 5, 0.05)
+    p = te.lcn(dev(pat), 5, 0.05)[0][0].contiguous()
+    ref = te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
+    h = te.prepare_pattern(p, 3, D, 9)
+    for rep in range(3):
+        x2 = (x + 0.0) if rep < 2 else x.flip(0).contiguous()        # the last call: other frames, same handle
+        got = te.xcorrvol_argmax(x2, p, D, 9, return_volume=True, algo="fast", prepared=h)
+        want = ref if rep < 2 else te.xcorrvol_argmax(x2, p, D, 9, return_volume=True, algo="fast")
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), rep
+        got_n = te.xcorrvol_argmax(x2, p, D, 9, algo="fast", prepared=h)
+        assert torch.equal(got_n[0], want[0])
+    pp = te.lcn(dev(np.stack([pat[0], pat[0][:, ::-1].copy(), pat[0]])), 5, 0.05)[0].contiguous()   # per-frame patterns
+    h2 = te.prepare_pattern(pp, 3, D, 9)
+    got = te.xcorrvol_argmax(x, pp, D, 9, return_volume=True, algo="fast", prepared=h2)
+    want = te.xcorrvol_argmax(x, pp, D, 9, return_volume=True, algo="fast")
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(RuntimeError):
+        te.xcorrvol_argmax(x[:2].contiguous(), p, D, 9, algo="fast", prepared=h)      # another frame count
