@@ -156,7 +156,7 @@ def proj_nn(xyz0, xyz1, K, patch_size):
 # --------------------------------------------------------------------------------------
 # NCC volume (reference: XCorrVolFunction, functions.py:59-74)
 # --------------------------------------------------------------------------------------
-def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):
+def _xcorrvol_impl(in0, in1, n_disps, block_size, algo, prepared=None):
     """in0 [N,C,H,W], in1 [C,H,W] | [N,C,H,W] -> [N,D,H,W]"""
     L = _lib.lib()
     dev = _same_device(in0, in1)
@@ -175,8 +175,11 @@ def _xcorrvol_impl(in0, in1, n_disps, block_size, algo):
     if algo == "fast" and not _ncc_fast_covers(in0.dtype, D, bs):
         algo = "exact"
     a = _ALGOS[algo]
-    ws_bytes = L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a)
-    ws = _workspace(ws_bytes, dev)
+    if prepared is not None:
+        _check_prepared(prepared, "xcorrvol_batch", a, in1, N, D, bs, dev)
+        ws, a = prepared.workspace, a | 0x100                        # CTD_PATTERN_PREPARED
+    else:
+        ws = _workspace(L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, bs, a), dev)
     if in0.dtype == torch.float32:
         st = L.ctd_xcorrvol_f32(_ptr(in0), _ptr(in1), stride1, _ptr(out), N, C, H, W, D, bs, a, _ptr(ws),
                                 ws.numel(), dev.index, _stream(dev))
@@ -207,14 +210,14 @@ def xcorrvol(in0, in1, n_disps, block_size, algo=None):
     return XCorrVolFunction.apply(in0, in1, n_disps, block_size, algo)
 
 
-def xcorrvol_batch(in0, in1, n_disps, block_size, algo=None):
+def xcorrvol_batch(in0, in1, n_disps, block_size, algo=None, prepared=None):
     """Additive: xcorrvol for a batch of frames in one launch.
-    in0 [N,C,H,W]; in1 [C,H,W] (shared pattern) or [N,C,H,W] -> [N,D,H,W]."""
+    in0 [N,C,H,W]; in1 [C,H,W] (shared pattern) or [N,C,H,W] -> [N,D,H,W].  `prepared`: see `prepare_pattern`."""
     _check(in0, "in0")
     _check(in1, "in1")
     if in0.dim() != 4 or in1.dim() not in (3, 4):
         raise RuntimeError("xcorrvol_batch expects in0 [N,C,H,W] and in1 [C,H,W] or [N,C,H,W]")
-    return _xcorrvol_impl(in0, in1, n_disps, block_size, algo or _default_algo())
+    return _xcorrvol_impl(in0, in1, n_disps, block_size, algo or _default_algo(), prepared)
 
 
 def argmax_disp(vol):
@@ -231,6 +234,13 @@ def argmax_disp(vol):
     st = _lib.lib().ctd_argmax_disp_f32(_ptr(v), _ptr(idx), _ptr(best), N, D, H, W, dev.index, _stream(dev))
     _lib.check(st, "argmax_disp")
     return (idx[0], best[0]) if squeeze else (idx, best)
+
+
+def _check_prepared(prepared, who, a, in1, N, D, bs, dev):
+    if (a != 1 or prepared.in1 is not in1 or prepared.n_frames != N or prepared.n_disps != D or prepared.block_size != bs
+            or prepared.workspace.device != dev):
+        raise RuntimeError("%s: `prepared` belongs to another pattern, frame count, shape or device "
+                           "(or the call does not take the fast path)" % who)
 
 
 class PreparedPattern:
@@ -292,10 +302,7 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
     need_vol = a == 1 and not L.ctd_xcorrvol_rank_supported(C, H, W, D, bs)
     vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if (return_volume or need_vol) else None
     if prepared is not None:
-        if (a != 1 or prepared.in1 is not in1 or prepared.n_frames != N or prepared.n_disps != D or prepared.block_size != bs
-                or prepared.workspace.device != dev):
-            raise RuntimeError("xcorrvol_argmax: `prepared` belongs to another pattern, frame count, shape or device "
-                               "(or algo is not 'fast')")
+        _check_prepared(prepared, "xcorrvol_argmax", a, in1, N, D, bs, dev)
         ws, a_flag = prepared.workspace, a | 0x100                   # CTD_PATTERN_PREPARED
     else:
         ws, a_flag = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, bs, a), dev), a

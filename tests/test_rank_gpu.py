@@ -187,6 +187,7 @@ def test_prepared_pattern_gives_the_same_results(te):
         assert all(torch.equal(a, b) for a, b in zip(got, want)), rep
         got_n = te.xcorrvol_argmax(x2, p, D, 9, algo="fast", prepared=h)
         assert torch.equal(got_n[0], want[0])
+        assert torch.equal(te.xcorrvol_batch(x2, p, D, 9, algo="fast", prepared=h), want[2])    # the plain volume call too
     pp = te.lcn(dev(np.stack([pat[0], pat[0][:, ::-1].copy(), pat[0]])), 5, 0.05)[0].contiguous()   # per-frame patterns
     h2 = te.prepare_pattern(pp, 3, D, 9)
     got = te.xcorrvol_argmax(x, pp, D, 9, return_volume=True, algo="fast", prepared=h2)
