@@ -135,6 +135,22 @@ def test_rank_full_size_goldens(te, oracle):
         assert np.array_equal(idx.cpu().numpy().astype(np.uint8), g["kin_argmax"]), rv
 
 
+def test_rank_config2_batch_one_round_plan(te):
+    """BASELINE config 2 as the bench runs it (16 frames: ONE round of 256 workgroups, 54-row bands, two-row chunks -- a
+    plan no smaller shape selects): volume + ranking, ranking alone and the plain volume against the reference-order
+    kernel on the bench workload, every pixel of every frame"""
+    from connecting_the_dots_amd import _lib
+    import ctypes
+    H, W, D, N = 432, 512, 128, 16
+    off = (ctypes.c_size_t * 5)()
+    assert _lib.lib().ctd_xcorrvol_rank_layout(N, H, W, D, 0, off) == 0 and (off[0], off[4]) == (54, 5)
+    fr = np.stack([workloads.uniform_frame(1234 + i, H, W) for i in range(N)])
+    pat = workloads.syn_dot_pattern(H, W, seed=42)[None, None]
+    x, _ = te.lcn(dev(fr), 5, 0.05)
+    p = te.lcn(dev(pat), 5, 0.05)[0][0].contiguous()
+    check_both_modes(te, x, p, D, "config 2, 16 frames")
+
+
 def test_rank_eps_negative_is_plain_fast_argmax(te):
     """rerank_eps < 0: no re-scoring; the key-ranked index must then hold a score within the key truncation of the
     fast volume's maximum"""
