@@ -20,7 +20,7 @@ def run(path):
     p, _ = te.lcn(pat, 5, 0.05)
     p = p[0].contiguous()
     L.ctd_kernel_timing_enable(1)
-    for _ in range(100):                # ~50 ms of the same work before timing: the card's clocks need it
+    for _ in range(int(os.environ.get("CTD_WARM_CALLS", "100"))):                # ~50 ms of the same work before timing: the card's clocks need it
         te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
     torch.cuda.synchronize()
     L.ctd_kernel_timing_collect(None, None)
