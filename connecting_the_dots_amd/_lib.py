@@ -53,6 +53,7 @@ SIGNATURES = {
     "ctd_disparity_loss_bwd_f32": (_c_int, [_vp] * 5 + [_c_int] * 3 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_geometric_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "ctd_geometric_fwd_f32": (_c_int, [_vp] * 9 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
+    "ctd_geometric_sym_fwd_f32": (_c_int, [_vp] * 9 + [_c_int] * 3 + [_c_float, _vp, _c_size_t, _vp, _c_int, _vp]),
     "ctd_geometric_bwd_f32": (_c_int, [_vp] * 10 + [_c_int, _vp] + [_c_int] * 3 + [_c_float, _c_int, _vp]),
     "ctd_pattern_loss_workspace_bytes": (_c_size_t, [_c_int] * 3),
     "ctd_pattern_loss_fwd_f32": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_c_float, _vp, _c_size_t, _c_int, _vp]),

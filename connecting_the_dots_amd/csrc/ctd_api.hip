@@ -426,6 +426,19 @@ int ctd_geometric_fwd_f32(const float* depth0, const float* depth1, const float*
                            workspace_bytes, (hipStream_t)stream);
 }
 
+int ctd_geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                              const float* t0, const float* R1, const float* t1, float* loss, int B, int H, int W,
+                              float clamp, void* workspace, size_t workspace_bytes, unsigned* ticket, int device,
+                              void* stream) {
+  if (!img_shape_ok(B, H, W) || H < 2 || W < 2 || !depth0 || !depth1 || !ray || !K || !R0 || !t0 || !R1 || !t1 || !loss ||
+      !ticket)
+    return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return geometric_sym_fwd_f32(depth0, depth1, ray, K, R0, t0, R1, t1, loss, B, H, W, clamp, workspace, workspace_bytes,
+                               ticket, (hipStream_t)stream);
+}
+
 int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
                           const float* t0, const float* R1, const float* t1, const float* grad_loss,
                           float* grad_depth0, int accumulate0, float* grad_depth1, int B, int H, int W, float clamp,

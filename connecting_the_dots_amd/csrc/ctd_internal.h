@@ -112,6 +112,9 @@ size_t geometric_workspace_bytes(int B, int H, int W);
 int geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
                       const float* t0, const float* R1, const float* t1, float* loss, int accumulate, int B, int H,
                       int W, float clamp, void* ws, size_t ws_bytes, hipStream_t s);
+int geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                          const float* t0, const float* R1, const float* t1, float* loss, int B, int H, int W, float clamp,
+                          void* ws, size_t ws_bytes, unsigned* ticket, hipStream_t s);
 int geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
                       const float* t0, const float* R1, const float* t1, const float* grad_loss, float* grad_depth0,
                       int accumulate0, float* grad_depth1, int B, int H, int W, float clamp, hipStream_t s);

@@ -323,6 +323,105 @@ __global__ __launch_bounds__(256) void geometric_fwd_kernel(const float* __restr
   block_partial(term, partials);
 }
 
+// Both directions of the symmetric loss in ONE launch and the final means by the LAST workgroup to finish.
+// Tiles of 64 x 4 pixels as in the one-direction kernel (tile z < B: depth0 -> view 1, else depth1 -> view 0 with the
+// poses swapped), dealt round-robin to the wavefronts of at most kGeoSymBlocks workgroups; every tile's partial sum goes to its own slot
+// (x fastest, then y, then z: direction 0 first, as one call has it), then the workgroup draws a ticket; the holder of
+// the last ticket sums the partials of each direction in the fixed order of finish_mean_kernel -- the result does not
+// depend on which workgroup that is and equals the two-call path bit for bit -- and leaves the tickets at zero.
+// Visibility without fences (a device-scope release fence writes back the whole L2 of the XCD: with one per workgroup
+// the launch took 260 us): the partials go out as device-scope atomic stores (written through to where every XCD sees
+// them), each wavefront waits for its own (vmcnt) before the workgroup draws its ticket, and the last workgroup reads
+// them with device-scope atomic loads.  Tickets in two
+// levels -- kGeoSymGroups group words, then one global word -- because 13 824 device-scope increments of ONE word took
+// 176 us (they serialise at ~12 ns apiece).  As two launches + two one-workgroup reductions the pair cost
+// 2 x 12.3 + 2 x 8.6 us of the config-3 step; the reductions were pure launch latency.
+constexpr int kGeoSymBlocks = 2048, kGeoSymGroups = 64;      // ticket words: [0] global, [1 .. kGeoSymGroups] groups
+
+__global__ __launch_bounds__(256) void geometric_sym_fwd_kernel(const float* __restrict__ depth0,
+                                                                const float* __restrict__ depth1,
+                                                                const float* __restrict__ ray, const float* __restrict__ K,
+                                                                const float* __restrict__ R0, const float* __restrict__ t0,
+                                                                const float* __restrict__ R1, const float* __restrict__ t1,
+                                                                float* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                                float* __restrict__ loss, int B, int H, int W, float clamp,
+                                                                double count) {
+  __shared__ bool s_last;
+  __shared__ double s_sum[256];
+  const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4;
+  const long n_dir = (long)tiles_x * tiles_y * B, n_tiles = 2 * n_dir;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a WAVEFRONT per tile, lane <-> column, the tile's four rows in the lane's registers (four independent chains of
+  // dependent loads in flight instead of one): row sums by shuffle, then row 0 + 1 + 2 + 3 -- the order block_partial
+  // adds its four wavefronts in
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
+    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y), z = (int)(tile / ((long)tiles_x * tiles_y));
+    const int w = tx * 64 + lane;
+    const bool rev = z >= B;
+    const int b = rev ? z - B : z;
+    const long plane = (long)b * H * W;
+    const Pose P = rev ? load_pose(K, R1, t1, R0, t0, b) : load_pose(K, R0, t0, R1, t1, b);
+    const float* da = rev ? depth1 : depth0;
+    const float* db = rev ? depth0 : depth1;
+    float term[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h = ty * 4 + k;
+      term[k] = 0.f;
+      if (w < W && h < H) {
+        const long q = (long)h * W + w;
+        const GeoPoint g = geo_forward(P, ray + q * 3, da[plane + q], db + plane, H, W);
+        term[k] = clamp > 0.f ? fminf(g.diff, clamp) : g.diff;
+      }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t += wave_sum(term[k]);
+    if (lane == 0) __hip_atomic_store(partials + tile, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's partials have been written where all XCDs see them
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned group = blockIdx.x % kGeoSymGroups;
+    const unsigned in_group = (gridDim.x - group + kGeoSymGroups - 1) / kGeoSymGroups;
+    bool last = __hip_atomic_fetch_add(ticket + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1u;
+    if (last) {
+      const unsigned n_groups = gridDim.x < (unsigned)kGeoSymGroups ? gridDim.x : (unsigned)kGeoSymGroups;
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1u;
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;                             // (workgroup-uniform)
+  // acquire side: invalidate what this CU / XCD may hold of the partials' lines (no write-back involved), then plain
+  // loads -- as device-scope atomic loads the 54 per thread went out one round trip at a time (42 us for the launch)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  float v[2];
+  for (int dir = 0; dir < 2; ++dir) {
+    double t = 0;
+    const float* pd = partials + dir * n_dir;
+    long i = threadIdx.x;
+    for (; i + 7 * 256 < n_dir; i += 8 * 256) {      // eight independent loads in flight, added in index order
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = pd[i + k * 256];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += (double)x[k];
+    }
+    for (; i < n_dir; i += 256) t += (double)pd[i];
+    s_sum[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) s_sum[threadIdx.x] += s_sum[threadIdx.x + st];
+      __syncthreads();
+    }
+    v[dir] = (float)(s_sum[0] / count);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = v[0] + v[1];
+  if (threadIdx.x <= kGeoSymGroups) __hip_atomic_store(ticket + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // backward: grad_depth0 written (every element), grad_depth1 ACCUMULATED with float atomics into a buffer the
 // caller zeroed (the bilinear scatter of ATen's grid_sample backward does the same)
 __global__ __launch_bounds__(256) void geometric_bwd_kernel(const float* __restrict__ depth0,
@@ -396,6 +495,18 @@ int geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray
   CTD_LAUNCH_CHECK();
   hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, loss_grid_blocks(B, H, W),
                      (double)B * H * W, loss, accumulate);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
+int geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
+                          const float* t0, const float* R1, const float* t1, float* loss, int B, int H, int W, float clamp,
+                          void* ws, size_t ws_bytes, unsigned* ticket, hipStream_t s) {
+  if (!ws || ws_bytes < geometric_workspace_bytes(2 * B, H, W) || !ticket) return CTD_ERR_WORKSPACE;
+  const long n_tiles = (long)ceil_div(W, 64) * ceil_div(H, 4) * 2 * B;
+  dim3 grid((unsigned)(n_tiles < kGeoSymBlocks ? n_tiles : kGeoSymBlocks)), block(256);
+  hipLaunchKernelGGL(geometric_sym_fwd_kernel, grid, block, 0, s, depth0, depth1, ray, K, R0, t0, R1, t1, (float*)ws, ticket,
+                     loss, B, H, W, clamp, (double)B * H * W);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

@@ -65,6 +65,19 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_TICKETS = {}
+
+
+def _ticket(dev):
+    """Zeroed device words (128 of them) per (device, stream) for kernels whose last workgroup finishes a reduction: they
+    take them at zero and leave them at zero (ctd_hip.h: ctd_geometric_sym_fwd_f32)."""
+    key = (dev.index, _stream(dev))
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(128, dtype=torch.int32, device=dev)
+    return t
+
+
 # --------------------------------------------------------------------------------------
 # Nearest-neighbour consistency ops (reference: NNFunction / CrossCheckFunction / ProjNNFunction,
 # functions.py:5-56; bindings ext_cuda.cpp:17-68)
@@ -728,15 +741,23 @@ class GeometricLossFunction(torch.autograd.Function):
                 t0.numel() != B * 3 or t1.numel() != B * 3:
             raise RuntimeError("geometric_loss: ray [H*W,3], K [3,3], R [B,3,3], t [B,3] expected")
         L = _lib.lib()
-        ws = _workspace(L.ctd_geometric_workspace_bytes(B, H, W), dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         c = float(clamp)
-        st = L.ctd_geometric_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1),
-                                     _ptr(loss), 0, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
-        _lib.check(st, "geometric_loss")
-        st = L.ctd_geometric_fwd_f32(_ptr(depth1), _ptr(depth0), _ptr(ray), _ptr(K), _ptr(R1), _ptr(t1), _ptr(R0), _ptr(t0),
-                                     _ptr(loss), 1, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
-        _lib.check(st, "geometric_loss")
+        if L.ctd_geometric_workspace_bytes(2 * B, H, W) > 0:
+            # both directions in one launch, the means formed by its last workgroup (tickets: zeroed words per stream)
+            ws = _workspace(L.ctd_geometric_workspace_bytes(2 * B, H, W), dev)
+            st = L.ctd_geometric_sym_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1),
+                                             _ptr(t1), _ptr(loss), B, H, W, c, _ptr(ws), ws.numel(), _ptr(_ticket(dev)),
+                                             dev.index, _stream(dev))
+            _lib.check(st, "geometric_loss")
+        else:
+            ws = _workspace(L.ctd_geometric_workspace_bytes(B, H, W), dev)
+            st = L.ctd_geometric_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1),
+                                         _ptr(loss), 0, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+            _lib.check(st, "geometric_loss")
+            st = L.ctd_geometric_fwd_f32(_ptr(depth1), _ptr(depth0), _ptr(ray), _ptr(K), _ptr(R1), _ptr(t1), _ptr(R0), _ptr(t0),
+                                         _ptr(loss), 1, B, H, W, c, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+            _lib.check(st, "geometric_loss")
         ctx.save_for_backward(depth0, depth1, ray, K, R0, t0, R1, t1)
         ctx.clamp = c
         return loss

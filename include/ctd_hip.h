@@ -246,6 +246,16 @@ int ctd_geometric_fwd_f32(const float* depth0, const float* depth1, const float*
                           const float* R0, const float* t0, const float* R1, const float* t1,
                           float* loss, int accumulate, int B, int H, int W, float clamp,
                           void* workspace, size_t workspace_bytes, int device, void* stream);
+/* Additive: BOTH directions (the module's tforward, model/networks.py:500-503) in one launch, the two means formed by the
+ * last workgroup to finish: loss[0] = mean(depth0 -> view 1) + mean(depth1 -> view 0), the same bits as the two
+ * ctd_geometric_fwd_f32 calls (accumulate 0, then 1 with the views swapped).
+ *   workspace: ctd_geometric_workspace_bytes(2 * B, H, W) bytes (contents irrelevant);
+ *   ticket: 65 4-byte device words (260 bytes) owned by the caller, ZERO before the first call on them; every call
+ *           leaves them zero.  Calls that may run concurrently (different streams) need tickets (and a workspace) each. */
+int ctd_geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K,
+                              const float* R0, const float* t0, const float* R1, const float* t1,
+                              float* loss, int B, int H, int W, float clamp, void* workspace,
+                              size_t workspace_bytes, unsigned* ticket, int device, void* stream);
 int ctd_geometric_bwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K,
                           const float* R0, const float* t0, const float* R1, const float* t1,
                           const float* grad_loss, float* grad_depth0, int accumulate0,

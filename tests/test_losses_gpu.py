@@ -97,3 +97,37 @@ def test_idx_to_depth_matches_disp_to_depth(te):
     assert got.dtype == torch.float32 and torch.equal(got, ref)
     with pytest.raises(RuntimeError):
         te.idx_to_depth(idx.to(torch.int32), 1.0)
+
+
+@pytest.mark.parametrize("B,H,W,clamp", [(1, 5, 7, -1.0), (3, 33, 130, 0.1), (15, 432, 512, 0.1)])
+def test_geometric_symmetric_launch_equals_the_two_calls(te, B, H, W, clamp):
+    """ctd_geometric_sym_fwd_f32 (both directions in one launch, means by the last workgroup): the same bits as
+    ctd_geometric_fwd_f32 called twice (accumulate 0 / 1, views swapped), call after call on the same ticket"""
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(B * 100 + H)
+    d0 = dev(1.0 + rs.rand(B, 1, H, W).astype(np.float32))
+    d1 = dev(1.0 + rs.rand(B, 1, H, W).astype(np.float32))
+    K = np.array([[0.9 * W, 0, W / 2.0], [0, 0.9 * W, H / 2.0], [0, 0, 1]], np.float32)
+    mod = te.ProjectionDepthSimilarityLoss(torch.from_numpy(K), torch.from_numpy(np.linalg.inv(K.astype(np.float64)).astype(np.float32)), H, W, clamp=clamp)
+    ray, Kd = mod.ray.cuda().contiguous(), dev(K)
+    R0 = dev(np.stack([np.eye(3, dtype=np.float32)] * B)); R1 = R0.clone()
+    R1[:, 0, 1] = 0.01; R1[:, 1, 0] = -0.01
+    t0 = dev(rs.randn(B, 3).astype(np.float32) * 0.02); t1 = dev(rs.randn(B, 3).astype(np.float32) * 0.02)
+    s = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(L.ctd_geometric_workspace_bytes(2 * B, H, W), dtype=torch.uint8, device="cuda")
+    two = torch.empty((), device="cuda")
+    p = lambda t: t.data_ptr()
+    assert L.ctd_geometric_fwd_f32(p(d0), p(d1), p(ray), p(Kd), p(R0), p(t0), p(R1), p(t1), p(two), 0, B, H, W, clamp, p(ws), ws.numel(), 0, s) == 0
+    assert L.ctd_geometric_fwd_f32(p(d1), p(d0), p(ray), p(Kd), p(R1), p(t1), p(R0), p(t0), p(two), 1, B, H, W, clamp, p(ws), ws.numel(), 0, s) == 0
+    ticket = torch.zeros(65, dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        ws.fill_(0xAB)                                   # stale partials of another call must not matter
+        one = torch.full((), float("nan"), device="cuda")
+        assert L.ctd_geometric_sym_fwd_f32(p(d0), p(d1), p(ray), p(Kd), p(R0), p(t0), p(R1), p(t1), p(one), B, H, W, clamp,
+                                           p(ws), ws.numel(), p(ticket), 0, s) == 0
+        assert torch.equal(one, two), (rep, one.item(), two.item())
+        assert int(ticket.abs().sum().item()) == 0
+    assert torch.equal(mod(d0, d1, R0, t0, R1, t1), two)           # the module takes the one-launch path
+    assert L.ctd_geometric_sym_fwd_f32(p(d0), p(d1), p(ray), p(Kd), p(R0), p(t0), p(R1), p(t1), p(two), B, H, W, clamp,
+                                       p(ws), 16, p(ticket), 0, s) != 0                  # workspace too small
