@@ -1601,15 +1601,22 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
         const float be[8] = {qb0[0], qb0[1], qb0[2], qb0[3], qb1[0], qb1[1], qb1[2], qb1[3]};
         const int h = r - TAIL;
         const bool row_out = (h >= h_lo) && (h < h_hi);           // wave-uniform
+        // 9-row sums as 3 x 3: t3 = rows r-2 .. r of the products, x = t3 of rows r, r-3, r-6.  The two OLD ring entries
+        // are added first and die there, so the new entry (p, t3) can take the register of the one it replaces: summed
+        // as (p + P') + P the new and the old value were live together and every ring slot cost a v_mov at the loop's
+        // back edge (48 of 979 vector instructions per 6 rows).
         float x[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+            float sP = P[j][i][(u + 1) % 2] + P[j][i][u % 2];
+            float sT = T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+            asm("" : "+v"(sP), "+v"(sT));                          // (formed before the slots are reused)
             const float p = av[i] * be[kS + (1 - j) + i];          // b[j][i] = slot kOff0 - j + i
-            const float t3 = p + P[j][i][(u + 1) % 2] + P[j][i][u % 2];
+            const float t3 = p + sP;
             P[j][i][u % 2] = p;
-            x[j][i] = t3 + T[j][i][(u + 3) % 6] + T[j][i][u % 6];
+            x[j][i] = t3 + sT;
             T[j][i][u % 6] = t3;
           }
         // previous output row's runner-up update (possibly of the previous chunk): its returns are in by now
