@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void rank_tail_kernel(float* __restrict__ vol,
                                                         int64_t* __restrict__ idx, float* __restrict__ best,
                                                         const unsigned char* __restrict__ flags, int frames, int D, int H,
                                                         int W, int bs, float eps, WorkList work, RunSource rsrc,
-                                                        const unsigned* __restrict__ counters,
+                                                        unsigned* __restrict__ counters,
                                                         const unsigned long long* __restrict__ run_rows,
                                                         const unsigned long long* __restrict__ flag_a,
                                                         const unsigned long long* __restrict__ flag_b, unsigned n_resolve,
@@ -358,6 +358,9 @@ __global__ __launch_bounds__(256) void rank_tail_kernel(float* __restrict__ vol,
     if (b < 2 * n_pair) { role = b & 1; rb = b >> 1; }
     else { role = n_resolve > n_runs ? 0 : 1; rb = b - n_pair; }
   }
+  // (nobody reads slot 0 in this launch -- the decode role takes the count from slot 3, ncc_fixup_kernel -- and the next
+  // call's pre-pass counts its listed frame windows from zero in it)
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = 0u;
   if (role == 0) {
     resolve_role<WORDS, VOL>(lds_dyn, vol, in0, in1, in1_frame_stride, idx, best, D, H, W, bs, eps, work, rsrc, rb, n_resolve,
                              kTailResolveWaves);

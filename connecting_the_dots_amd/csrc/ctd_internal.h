@@ -33,7 +33,8 @@ struct RankPlan {
   // what the tail kernel (runs | decode | resolve roles, argmax_rerank.hip) needs of the volume pass's workspace
   const float* run_vals;      // [frames][H][D] exact values of the listed fully clamped runs
   const unsigned long long* run_rows;
-  const unsigned* counters;   // [1] listed pattern windows, [2] listed run rows
+  unsigned* counters;         // [0] listed frame windows (the tail kernel clears it), [1] listed pattern windows, [2] listed run
+                              // rows, [3] copy of [0] made by the ranked fix-up kernel for the tail kernel
   const unsigned long long *flag_a, *flag_b;   // lists of the listed frame / pattern windows
   const float* v1;            // pattern reciprocal-deviation planes (0 = listed window), row pitch W1, column x at x + xoff
   int W1, xoff;

@@ -108,7 +108,7 @@ __device__ inline void decode_role(unsigned long long* __restrict__ idx, float* 
   const int lane = threadIdx.x & 63;
   // listed FRAME windows: every score of their pixel was a placeholder, so the pixel is normally on the work list
   // (all its keys tie); a pixel with a single score (D = 1, or w = 0 of a one-disparity run) is not -- decode it here
-  const unsigned n_a = counters[0];
+  const unsigned n_a = counters[3];               // (slot 0's value, copied by the ranked fix-up kernel; slot 0 itself is being cleared)
   for (unsigned j = wave * 64 + lane; j < n_a; j += n_waves * 64) {
     const unsigned long long e = list_a[j];
     const long pix = ((long)(e >> 40) * H + (long)((e >> 20) & 0xFFFFF)) * W + ((long)(e & 0xFFFFF) - 0x80000);

@@ -412,7 +412,7 @@ __device__ __forceinline__ void fixup_grouped_item(const float* __restrict__ in0
 template <int BS>
 __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
                                                         long in1_frame_stride, float* __restrict__ out,
-                                                        const unsigned* __restrict__ counters,
+                                                        unsigned* __restrict__ counters,
                                                         const unsigned long long* __restrict__ list_a,
                                                         const unsigned long long* __restrict__ list_b,
                                                         float* __restrict__ run_vals,
@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256, 2) void ncc_fixup_kernel(const float* __restri
   float* sSq = sS + bs * span;
   const long HW = (long)H * W;
   const unsigned n_a = counters[0], n_b = counters[1];
+  // ranked calls: the tail kernel reads the number of listed frame windows from slot 3 and clears slot 0 for the next
+  // call's pre-pass (which counts in it) -- no memset launch in front of a call on a prepared pattern
+  if (best && blockIdx.x == 0 && threadIdx.x == 0) counters[3] = n_a;
   const unsigned per_b = in1_frame_stride == 0 ? (unsigned)frames : 1u;   // a shared pattern window meets every frame
   // single channel, shared pattern, SPAN small enough for the prefetch registers: kFixFrames frames per item
   const bool grouped = per_b > 1u && C == 1 && bs * span <= 64 * kFixSpanRegs;
@@ -2243,7 +2246,7 @@ int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int fr
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
-  CTD_HIP_TRY(hipMemsetAsync(ws.counters + 1, 0, 8, stream));
+  CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
   const PrepassJob ja = {in1, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, 0, ws.counters, ws.flag_a, 0, W,
                          nullptr, nullptr, -(double)(bs * bs)};                       // (no frame images in this launch)
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
@@ -2281,7 +2284,8 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   if (rank && !rank->idx) return CTD_ERR_INVALID_ARG;
   // counters: [0] listed frame windows, [1] listed pattern windows, [2] listed run rows -- the last two belong to the
   // pattern and survive when it was prepared
-  CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, pattern_prepared ? 4 : 16, stream));
+  // (a ranked call on a prepared pattern finds [0] at zero: the prepare call and every ranked call's tail kernel leave it so)
+  if (!(rank && pattern_prepared)) CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, pattern_prepared ? 4 : 16, stream));
   // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
@@ -2300,8 +2304,10 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
     default: return CTD_ERR_UNSUPPORTED;
   }
   if (st || rank) return st;
-  return launch_fixup(in0, in1, in1_frame_stride, out, frames, C, H, W, D, bs, ws, per_frame, nullptr, nullptr,
-                      (unsigned*)workspace, stream);
+  st = launch_fixup(in0, in1, in1_frame_stride, out, frames, C, H, W, D, bs, ws, per_frame, nullptr, nullptr,
+                    (unsigned*)workspace, stream);
+  if (st == CTD_OK && pattern_prepared) CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 4, stream));   // (see above: [0] stays zero between calls)
+  return st;
 }
 
 // Second half of a ranked call, after the all-D kernel: fix-up of the listed windows (volume patch when there is one,
