@@ -258,16 +258,17 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
         sA[i] = xa;
         sAq[i] = xa / bs2f;
       }
-      for (int i0 = lane; i0 < bs * span; i0 += 64 * 8) {          // 8 independent loads in flight per lane
-        float t[8];
+      constexpr int NB = 20;                  // block 9, D <= 128: all 1224 elements in ONE round trip (8 deep: tail kernel +2 us)
+      for (int i0 = lane; i0 < bs * span; i0 += 64 * NB) {         // NB independent loads in flight per lane
+        float t[NB];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < NB; ++k) {
           const int i = min(i0 + 64 * k, bs * span - 1);
           const int bh = i / span, c = i - bh * span;
           t[k] = b[(long)clampi(hj + bh - half, 0, H - 1) * W + clampi(wj - half - (D - 1) + c, 0, W - 1)];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NB; ++k)
           if (i0 + 64 * k < bs * span) {
             sB[i0 + 64 * k] = t[k];
             sBq[i0 + 64 * k] = t[k] / bs2f;
