@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="tracks per GPU (reference: train_batch_size 8)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen searches its kernels per shape")
+    ap.add_argument("--channels-last", action="store_true", help="network weights and activations in NHWC")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # self-launch: this parent never touches a GPU
         from connecting_the_dots_amd import sharding
@@ -66,7 +68,11 @@ def main():
         pats.append(te.lcn(p.contiguous(), 5, 0.05)[0])
         p = F.avg_pool2d(p, 2)
     torch.manual_seed(0)
-    tr = TrackTrainer(DispEdgeNet(2, D), pats, K, baseline, [focal / 2 ** s for s in range(4)], process_group=pg,
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    net = DispEdgeNet(2, D)
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    tr = TrackTrainer(net, pats, K, baseline, [focal / 2 ** s for s in range(4)], process_group=pg,
                       device_ids=[dev_index] if pg is not None else None)
     for it in range(args.iters):
         if it == args.warmup:
