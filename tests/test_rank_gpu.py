@@ -211,3 +211,21 @@ def test_prepared_pattern_gives_the_same_results(te):
     assert all(torch.equal(a, b) for a, b in zip(got, want))
     with pytest.raises(RuntimeError):
         te.xcorrvol_argmax(x[:2].contiguous(), p, D, 9, algo="fast", prepared=h)      # another frame count
+
+
+@pytest.mark.parametrize("N,H,W,D", [(1, 21, 260, 130), (2, 40, 516, 33), (5, 12, 64, 256), (1, 9, 8, 3)])
+def test_prepared_pattern_shapes(te, N, H, W, D):
+    """prepared == unprepared on ragged shapes (D past one 128-disparity round, widths off the 256-column tiles, one
+    frame), ranked with / without a volume and plain, twice in a row on the same handle"""
+    rs = np.random.RandomState(N + H + W + D)
+    A = dev(rs.randn(N, 1, H, W).astype(np.float32))
+    flat = rs.randn(1, H, W).astype(np.float32)
+    flat[:, H // 3:H // 3 + 9, :12] = 0.25                       # a flat patch at the left border: listed windows and runs
+    B = dev(flat)
+    want = te.xcorrvol_argmax(A, B, D, 9, return_volume=True, algo="fast")
+    h = te.prepare_pattern(B, N, D, 9)
+    for _ in range(2):
+        got = te.xcorrvol_argmax(A, B, D, 9, return_volume=True, algo="fast", prepared=h)
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+        assert torch.equal(te.xcorrvol_argmax(A, B, D, 9, algo="fast", prepared=h)[0], want[0])
+        assert torch.equal(te.xcorrvol_batch(A, B, D, 9, algo="fast", prepared=h), want[2])
