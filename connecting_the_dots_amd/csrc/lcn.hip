@@ -16,9 +16,11 @@
 
 namespace ctd {
 
-constexpr int kLcnTW = 64;
-constexpr int kLcnTH = 16;
-constexpr int kLcnRows = 4;   // block = 64 x 4 threads, each thread owns kLcnTH / 4 CONSECUTIVE output rows
+constexpr int kLcnTW = 32;
+constexpr int kLcnTH = 32;
+constexpr int kLcnRows = 8;   // block = 32 x 8 threads, each thread owns kLcnTH / kLcnRows CONSECUTIVE output rows
+// (32 x 32 tiles: 42 staged rows per 32 outputs instead of 26 per 16 -- a fifth less of the f64 row pass -- and 28.6 KB of
+// LDS = five workgroups per CU instead of four: 26.8 -> 25.6 us on 16 x 432 x 512, tools/ab_lcn.sh)
 constexpr int kLcnHC = 8;     // output columns per item of the horizontal pass
 
 __device__ inline int reflect_idx(int i, int n) {

@@ -74,6 +74,11 @@ struct PrepassJob {
   unsigned long long* run_rows;
   double mean_scale;          // out_mean = mean_scale * (window mean - cval): -bs^2 for the frames (the kernels' n*ma*mb
                               // term then needs no multiply of its own), 1 for the pattern
+  int pitch, o_off, halo;     // output row pitch and column offset of xi = 0; halo > 0: the planes carry `halo` replicate
+                              // columns either side of the W_out computed ones, and out_img's are filled here (copies of
+                              // columns 0 and W_out - 1; the statistics planes' halo columns are never read).  The frames'
+                              // planes: computing the halo columns as windows of their own made a ninth column of
+                              // workgroups for 8 of 520 columns.
 };
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
@@ -191,11 +196,18 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     const float vf = (float)(var > 0 ? var : 1.0);
     float rdev = __builtin_amdgcn_rsqf(vf);
     rdev = fmaf(0.5f * rdev, fmaf(-vf * rdev, rdev, 1.f), rdev);
-    const long o = ((long)img_idx * H + h) * W_out + xi;
+    const long o = ((long)img_idx * H + h) * jp.pitch + jp.o_off + xi;
     const int col = xi + x_start;
     out_mean[o] = (float)(jp.mean_scale * mc);
     out_dev[o] = listed ? 0.f : rdev;
-    out_img[o] = tile[(r + half) * TCc + tx + half] - cval;
+    const float centred = tile[(r + half) * TCc + tx + half] - cval;
+    out_img[o] = centred;
+    if (jp.halo > 0) {
+      if (xi == 0)
+        for (int k = 1; k <= jp.halo; ++k) out_img[o - k] = centred;
+      if (xi == W_out - 1)
+        for (int k = 1; k <= jp.halo; ++k) out_img[o + k] = centred;
+    }
     if (listed && col >= col_lo && col < col_hi) {
       flag_list[atomicAdd(n_flag, 1u)] = ((unsigned long long)img_idx << 40) | ((unsigned long long)h << 20) |
                                          (unsigned long long)(col + 0x80000);
@@ -2247,10 +2259,10 @@ int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int fr
   FastWorkspace ws = fast_workspace(workspace, frames, C, H, W, D, per_frame);
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
-  const PrepassJob ja = {in1, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, 0, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr, -(double)(bs * bs)};                       // (no frame images in this launch)
+  const PrepassJob ja = {in1, (long)H * W, ws.ac, ws.m0, ws.v0, 0, W, 0, ws.counters, ws.flag_a, 0, W,
+                         nullptr, nullptr, -(double)(bs * bs), ws.Wp, 4, 4};          // (no frame images in this launch)
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0};
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0, ws.W1, 0, 0};
   return launch_prepass(ja, jb, H, W, bs, nullptr, stream);
 }
 
@@ -2289,11 +2301,11 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   // window statistics of the frames (per pixel) and of the pattern (per unclamped window-centre column
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
-  const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, -4, ws.Wp, frames * C, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr, -(double)(bs * bs)};
+  const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, 0, W, frames * C, ws.counters, ws.flag_a, 0, W,
+                         nullptr, nullptr, -(double)(bs * bs), ws.Wp, 4, 4};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1,
                          pattern_prepared ? 0 : (per_frame ? frames : 1) * C, ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W,
-                         ws.counters + 2, ws.run_rows, 1.0};
+                         ws.counters + 2, ws.run_rows, 1.0, ws.W1, 0, 0};
   int st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
   if (st) return st;
   switch (bs) {

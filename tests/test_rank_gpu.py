@@ -229,3 +229,30 @@ def test_prepared_pattern_shapes(te, N, H, W, D):
         assert all(torch.equal(a, b) for a, b in zip(got, want))
         assert torch.equal(te.xcorrvol_argmax(A, B, D, 9, algo="fast", prepared=h)[0], want[0])
         assert torch.equal(te.xcorrvol_batch(A, B, D, 9, algo="fast", prepared=h), want[2])
+
+
+@pytest.mark.parametrize("C", [1, 2])
+def test_workspace_contents_do_not_matter(te, C):
+    """the planes of the pre-pass have columns nobody computes (halo columns of the statistics planes, alignment padding):
+    a workspace full of NaN bit patterns gives the same volume / indices as one full of zeros"""
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    N, H, W, D = 2, 40, 260, 40
+    rs = np.random.RandomState(77 + C)
+    A = dev(rs.randn(N, C, H, W).astype(np.float32)); B = dev(rs.randn(C, H, W).astype(np.float32))
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fill in (0x00, 0xFF):
+        vol = torch.empty((N, D, H, W), device="cuda")
+        if C == 1:
+            ws = torch.full((L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, 9, 1),), fill, dtype=torch.uint8, device="cuda")
+            idx = torch.empty((N, H, W), dtype=torch.int64, device="cuda"); best = torch.empty((N, H, W), device="cuda")
+            assert L.ctd_xcorrvol_argmax_f32(A.data_ptr(), B.data_ptr(), 0, vol.data_ptr(), idx.data_ptr(), best.data_ptr(), N, C, H, W, D, 9,
+                                             1, 1e-5, ws.data_ptr(), ws.numel(), 0, s) == 0
+            outs.append((vol, idx, best))
+        else:
+            ws = torch.full((L.ctd_xcorrvol_workspace_bytes(N, C, H, W, D, 9, 1),), fill, dtype=torch.uint8, device="cuda")
+            assert L.ctd_xcorrvol_f32(A.data_ptr(), B.data_ptr(), 0, vol.data_ptr(), N, C, H, W, D, 9, 1, ws.data_ptr(), ws.numel(), 0, s) == 0
+            outs.append((vol,))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert bool(torch.isfinite(outs[1][0]).all())
