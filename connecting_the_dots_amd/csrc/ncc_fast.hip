@@ -53,7 +53,7 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // pre-pass: (mean, sqrt(sum of squared deviations)) of the clamped bs x bs window centred
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
-constexpr int kSTW = 32, kSTH = 32, kSRows = 8;   // (64 x 16 x 4: 36.9 instead of 35.1 us -- a fifth more rows staged and summed per output)
+constexpr int kSTW = 32, kSTH = 24, kSRows = 8;   // (A/B, rocprofv3, with the pattern job: 64 x 16: 36.9 us, 32 x 32: 35.1, 32 x 24: 34.0, 32 x 16: 37.1, 32 x 48: 39.4)
 constexpr double kDevFloor = 7e-2;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 2.1e-6 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 
