@@ -267,10 +267,11 @@ def run_config4(args):
     pat = torch.from_numpy(workloads.syn_dot_pattern(H4, W4, seed=42)).to(device).reshape(1, 1, H4, W4)
     pat_lcn = te.lcn(pat.contiguous(), LCN_RADIUS, LCN_EPS)[0][0].contiguous()            # [1, H, W]
     bpp = 4.0 + 8.0 / D4
+    prepared = te.prepare_pattern(pat_lcn, frames_n, D4, BS)     # the pattern half of the matcher's pre-pass, once per run
 
     def step():
         x, _ = te.lcn(fr, LCN_RADIUS, LCN_EPS)
-        idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D4, BS, return_volume=True)
+        idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D4, BS, return_volume=True, prepared=prepared)
         cen = te.costvol(x[:, 0], pat_lcn[0], D4, BS, "census_sad", 0.5, algo="fast")
         return x, idx, vol, cen
 
