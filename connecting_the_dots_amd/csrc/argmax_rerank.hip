@@ -238,7 +238,10 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
     }
     float eb = 0.f;
     int ei = 0x7fffffff;
-    if (n_cand > 1 && pre) {
+    // with a volume a single candidate is final and its (patched) score is read back; without one the exact score of a
+    // lone candidate still has to be formed (D = 1 with a listed window: the ranking only saw the placeholder)
+    const bool rescore = VOL ? n_cand > 1 : n_cand >= 1;            // wave-uniform
+    if (rescore && pre) {
 #pragma unroll
       for (int k = 0; k < kPreA; ++k)
         if (lane + 64 * k < bs * bs) {
@@ -251,7 +254,7 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
           sB[lane + 64 * k] = tb[k];
           sBq[lane + 64 * k] = tb[k] / bs2f;
         }
-    } else if (n_cand > 1) {
+    } else if (rescore) {
       for (int i = lane; i < bs * bs; i += 64) {
         const int bh = i / bs, bw = i - bh * bs;
         const float xa = a[(long)clampi(hj + bh - half, 0, H - 1) * W + clampi(wj + bw - half, 0, W - 1)];
@@ -278,7 +281,7 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
     // Exact re-scoring, lane <-> candidate (ascending d): every lane runs the reference's serial accumulations for
     // its own candidate out of LDS (a whole-wave evaluation of one candidate at a time, fed by v_readlane, costs
     // ~15 us per candidate; this costs ~3 us for all of them).  Then the lowest d among the best exact scores.
-    if (n_cand > 1) {
+    if (rescore) {
       for (int c0 = 0; c0 < n_cand; c0 += 64) {
         int my_d = -1, k = 0;
 #pragma unroll
@@ -310,7 +313,7 @@ __device__ __forceinline__ void resolve_role(float* lds_resolve, const float* __
       idx[pj] = ei;
       if (best) {
         if constexpr (VOL) best[pj] = (run_listed && ei >= d_clamped) ? rv : v[(long)(rsrc.run_vals ? min(ei, d_clamped) : ei) * HW];
-        else if (n_cand > 1) best[pj] = eb;                  // no fast score exists: the reference-order one
+        else if (rescore) best[pj] = eb;                     // no fast score exists: the reference-order one
       }
     }
   }

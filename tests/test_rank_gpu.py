@@ -256,3 +256,13 @@ def test_workspace_contents_do_not_matter(te, C):
             outs.append((vol,))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
     assert bool(torch.isfinite(outs[1][0]).all())
+
+
+def test_rank_single_disparity_with_listed_windows(te):
+    """D = 1 with flat patches (found by tools/fuzz_rank.py): the lone candidate of a listed window is still re-scored when
+    no volume is materialised -- the returned best score is the exact one, not the ranking's placeholder"""
+    rs = np.random.RandomState(241)
+    N, H, W = 3, 56, 396
+    a = rs.randn(N, 1, H, W).astype(np.float32); b = rs.randn(1, H, W).astype(np.float32)
+    b[:, 10:22, 40:54] = 0.3; b[:, : H // 2, :10] = 0.125; a[1, :, 30:40, 100:111] = -0.7
+    check_both_modes(te, dev(a), dev(b), 1, "D = 1, flat patches")
