@@ -74,6 +74,7 @@ struct PrepassJob {
   unsigned long long* run_rows;
   double mean_scale;          // out_mean = mean_scale * (window mean - cval): -bs^2 for the frames (the kernels' n*ma*mb
                               // term then needs no multiply of its own), 1 for the pattern
+  double flag_ratio;          // list a window when F - 1 > flag_ratio: kFlagRatio / C (the channels' errors add up in the sum)
   int pitch, o_off, halo;     // output row pitch and column offset of xi = 0; halo > 0: the planes carry `halo` replicate
                               // columns either side of the W_out computed ones, and out_img's are filled here (copies of
                               // columns 0 and W_out - 1; the statistics planes' halo columns are never read).  The frames'
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     // what the ranking does about placeholders: see the all-D kernel).
     const double mc = mean - (double)cval;
     const bool flat = 4e-8 * n * mean * mean > var || var < kDevFloor * kDevFloor;
-    const bool listed = flat || n * mc * mc > kFlagRatio * var;
+    const bool listed = flat || n * mc * mc > jp.flag_ratio * var;
     // reciprocal deviation (see ncc_inv_norm): v_rsq_f32 and one Newton step in f32, 1e-7 relative -- the f64 square
     // root and the two f64 divisions this line and `mean` used to cost were 60 % of the kernel's instructions
     const float vf = (float)(var > 0 ? var : 1.0);
@@ -2260,9 +2261,9 @@ int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int fr
   if (workspace == nullptr || workspace_bytes < ws.bytes) return CTD_ERR_WORKSPACE;
   CTD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 16, stream));
   const PrepassJob ja = {in1, (long)H * W, ws.ac, ws.m0, ws.v0, 0, W, 0, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr, -(double)(bs * bs), ws.Wp, 4, 4};          // (no frame images in this launch)
+                         nullptr, nullptr, -(double)(bs * bs), kFlagRatio / C, ws.Wp, 4, 4};   // (no frame images in this launch)
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1, (per_frame ? frames : 1) * C,
-                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0, ws.W1, 0, 0};
+                         ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W, ws.counters + 2, ws.run_rows, 1.0, kFlagRatio / C, ws.W1, 0, 0};
   return launch_prepass(ja, jb, H, W, bs, nullptr, stream);
 }
 
@@ -2302,10 +2303,10 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   // x = w - d; windows x <= -(bs-1-bs/2) are all the same fully clamped window and are listed once), one launch
   if (per_frame && in1_frame_stride != (long)C * H * W) return CTD_ERR_INVALID_ARG;
   const PrepassJob ja = {in0, (long)H * W, ws.ac, ws.m0, ws.v0, 0, W, frames * C, ws.counters, ws.flag_a, 0, W,
-                         nullptr, nullptr, -(double)(bs * bs), ws.Wp, 4, 4};
+                         nullptr, nullptr, -(double)(bs * bs), kFlagRatio / C, ws.Wp, 4, 4};
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1,
                          pattern_prepared ? 0 : (per_frame ? frames : 1) * C, ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W,
-                         ws.counters + 2, ws.run_rows, 1.0, ws.W1, 0, 0};
+                         ws.counters + 2, ws.run_rows, 1.0, kFlagRatio / C, ws.W1, 0, 0};
   int st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
   if (st) return st;
   switch (bs) {

@@ -1,0 +1,34 @@
+"""Random-shape soak of the fast NCC volume (every kernel family: all-D, tile-256 multi-channel, wide / narrow fallbacks for
+W % 4 != 0 and block sizes 3 / 5 / 7) against the reference-order kernel:   python tools/fuzz_volume.py [cases] [seed]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from connecting_the_dots_amd import torchext as te
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad, t0 = 0, time.time()
+for case in range(cases):
+    N = int(rs.randint(1, 4)); C = int(rs.choice([1, 1, 2, 3])); H = int(rs.randint(1, 70)); W = int(rs.randint(1, 560))
+    D = int(rs.randint(1, 200)); bs = int(rs.choice([3, 5, 7, 9, 9, 9]))
+    per_frame = bool(rs.randint(0, 2))
+    a = rs.randn(N, C, H, W).astype(np.float32) + (5.0 if rs.randint(0, 3) == 0 else 0.0)
+    b = rs.randn(*((N, C, H, W) if per_frame else (C, H, W))).astype(np.float32)
+    if rs.randint(0, 2):
+        b[..., : max(1, H // 2), : min(W, 12)] = 0.25
+        a[0, :, H // 3: H // 3 + 9, W // 2: W // 2 + 9] = -1.5
+    A = torch.from_numpy(a).cuda(); B = torch.from_numpy(b).cuda()
+    ve = te.xcorrvol_batch(A, B, D, bs, algo="exact")
+    vf = te.xcorrvol_batch(A, B, D, bs, algo="fast")
+    err = (vf - ve).abs() - (ve.abs() * 1e-5 + 1e-6)
+    ok = bool((err <= 0).all()) and bool(torch.isfinite(vf).all())
+    if ok and C == 1 and not per_frame and bs == 9:
+        h = te.prepare_pattern(B, N, D, bs)
+        ok = torch.equal(te.xcorrvol_batch(A, B, D, bs, algo="fast", prepared=h), vf)
+    if not ok:
+        bad += 1
+        print("case %d N=%d C=%d H=%d W=%d D=%d bs=%d per_frame=%d: max excess %g" % (case, N, C, H, W, D, bs, per_frame, float(err.max())), flush=True)
+    if case % 500 == 499:
+        print("... %d cases, %d bad, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
+print("fuzz_volume: %d cases, %d bad" % (cases, bad))
+sys.exit(1 if bad else 0)
