@@ -31,7 +31,7 @@ def test_lcn_vs_reference_golden(te):
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 32, 5), (1, 40, 53, 5), (3, 17, 130, 2), (1, 432, 512, 5), (1, 12, 13, 11),
-                                   (1, 7, 300, 0)])
+                                   (1, 7, 300, 0), (2, 33, 65, 5), (1, 64, 96, 5), (1, 31, 31, 5), (1, 97, 34, 3)])
 def test_lcn_bit_exact_vs_oracle(te, oracle, shape):
     N, H, W, r = shape
     rs = np.random.RandomState(N * H + W)
