@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void geometric_fwd_kernel(const float* __restr
 // levels -- kGeoSymGroups group words, then one global word -- because 13 824 device-scope increments of ONE word took
 // 176 us (they serialise at ~12 ns apiece).  As two launches + two one-workgroup reductions the pair cost
 // 2 x 12.3 + 2 x 8.6 us of the config-3 step; the reductions were pure launch latency.
-constexpr int kGeoSymBlocks = 2048, kGeoSymGroups = 64;      // ticket words: [0] global, [1 .. kGeoSymGroups] groups
+constexpr int kGeoSymBlocks = 4096, kGeoSymGroups = 64;      // (a tile per wavefront up to 16 K tiles; 2048: +1.3 us at config 3) ticket words: [0] global, [1 .. kGeoSymGroups] groups
 
 __global__ __launch_bounds__(256) void geometric_sym_fwd_kernel(const float* __restrict__ depth0,
                                                                 const float* __restrict__ depth1,
