@@ -47,7 +47,7 @@ void timing_end(hipStream_t stream, int columns) {
 
 extern "C" {
 
-int ctd_version(void) { return 2; }
+int ctd_version(void) { return 3; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;

@@ -38,7 +38,7 @@ enum ctd_status {
   CTD_ERR_HIP = 1000           /* 1000 + hipError_t of the failing runtime call           */
 };
 
-int ctd_version(void);                       /* ABI version, currently 2 (2: ranked argmax inside the all-D volume kernel; its workspace is ctd_xcorrvol_argmax_workspace_bytes()) */
+int ctd_version(void);                       /* ABI version, currently 3 (2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
 const char* ctd_status_string(int status);
 
 /* --------------------------------------------------------------------------------------

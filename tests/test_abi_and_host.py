@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from connecting_the_dots_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().ctd_version() == 2
+    assert _lib.lib().ctd_version() == 3
     assert _lib.lib().ctd_status_string(1) == b"invalid argument"
 
 
