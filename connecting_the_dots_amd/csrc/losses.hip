@@ -34,11 +34,24 @@ __device__ inline void block_partial(float v, float* __restrict__ partials) {
   }
 }
 
+constexpr int kGeoGroup = 4;    // tiles per f64 unit sum of the geometric loss (finish_mean_kernel's `group` for it)
+
+// `group`: partials are first summed (f64, index order) in groups of that many consecutive ones, thread t then adds groups
+// t, t + 256, ... -- 1 for most losses; the geometric loss uses 4, the order its one-launch kernel sums in (a workgroup
+// of four tiles publishes one f64 sum there)
 __global__ __launch_bounds__(256) void finish_mean_kernel(const float* __restrict__ partials, long n, double count,
-                                                          float* __restrict__ out, int accumulate) {
+                                                          float* __restrict__ out, int accumulate, int group = 1) {
   __shared__ double s[256];
   double t = 0;
-  for (long i = threadIdx.x; i < n; i += 256) t += (double)partials[i];
+  if (group <= 1) {
+    for (long i = threadIdx.x; i < n; i += 256) t += (double)partials[i];
+  } else {
+    for (long u = threadIdx.x; u * group < n; u += 256) {
+      double q = 0;
+      for (int k = 0; k < group && u * group + k < n; ++k) q += (double)partials[u * group + k];
+      t += q;
+    }
+  }
   s[threadIdx.x] = t;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
@@ -325,63 +338,76 @@ __global__ __launch_bounds__(256) void geometric_fwd_kernel(const float* __restr
 
 // Both directions of the symmetric loss in ONE launch and the final means by the LAST workgroup to finish.
 // Tiles of 64 x 4 pixels as in the one-direction kernel (tile z < B: depth0 -> view 1, else depth1 -> view 0 with the
-// poses swapped), dealt round-robin to the wavefronts of at most kGeoSymBlocks workgroups; every tile's partial sum goes to its own slot
-// (x fastest, then y, then z: direction 0 first, as one call has it), then the workgroup draws a ticket; the holder of
-// the last ticket sums the partials of each direction in the fixed order of finish_mean_kernel -- the result does not
-// depend on which workgroup that is and equals the two-call path bit for bit -- and leaves the tickets at zero.
+// poses swapped; x fastest, then y, then z, as one call numbers them), a wavefront per tile.  A work unit = kGeoGroup
+// consecutive tiles of ONE direction = the four wavefronts of a workgroup; it publishes the f64 sum of its tiles' f32
+// partials (tile order), then the workgroup draws a ticket; the holder of the last ticket adds the units of each
+// direction -- thread t units t, t + 256, ..., then the tree of finish_mean_kernel, which sums the one-direction
+// kernel's partials in the same groups (its `group` argument): the result does not depend on which workgroup finishes
+// last and equals the two-call path bit for bit.  The tickets are left at zero.
 // Visibility without fences (a device-scope release fence writes back the whole L2 of the XCD: with one per workgroup
-// the launch took 260 us): the partials go out as device-scope atomic stores (written through to where every XCD sees
-// them), each wavefront waits for its own (vmcnt) before the workgroup draws its ticket, and the last workgroup reads
-// them with device-scope atomic loads.  Tickets in two
-// levels -- kGeoSymGroups group words, then one global word -- because 13 824 device-scope increments of ONE word took
-// 176 us (they serialise at ~12 ns apiece).  As two launches + two one-workgroup reductions the pair cost
-// 2 x 12.3 + 2 x 8.6 us of the config-3 step; the reductions were pure launch latency.
-constexpr int kGeoSymBlocks = 4096, kGeoSymGroups = 64;      // (a tile per wavefront up to 16 K tiles; 2048: +1.3 us at config 3) ticket words: [0] global, [1 .. kGeoSymGroups] groups
+// the launch took 260 us): the unit sums go out as device-scope atomic stores (written through to where every XCD sees
+// them), awaited (vmcnt) before the ticket is drawn; the last workgroup reads them behind an acquire-only fence (as
+// device-scope atomic loads they went out one round trip at a time).  Tickets in two levels -- kGeoSymGroups group
+// words, then one global word -- because 13 824 device-scope increments of ONE word took 176 us (~12 ns apiece,
+// serialised).  Units of four tiles instead of single tiles: a quarter of the values for the last workgroup to read.
+// As two launches + two one-workgroup reductions the pair cost 2 x 12.3 + 2 x 8.6 us of the config-3 step.
+constexpr int kGeoSymBlocks = 4096, kGeoSymGroups = 64;      // ticket words: [0] global, [1 .. kGeoSymGroups] groups
 
 __global__ __launch_bounds__(256) void geometric_sym_fwd_kernel(const float* __restrict__ depth0,
                                                                 const float* __restrict__ depth1,
                                                                 const float* __restrict__ ray, const float* __restrict__ K,
                                                                 const float* __restrict__ R0, const float* __restrict__ t0,
                                                                 const float* __restrict__ R1, const float* __restrict__ t1,
-                                                                float* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                                double* __restrict__ unit_sums, unsigned* __restrict__ ticket,
                                                                 float* __restrict__ loss, int B, int H, int W, float clamp,
                                                                 double count) {
+  static_assert(kGeoGroup == 4, "a unit is the four wavefronts of a workgroup");
   __shared__ bool s_last;
+  __shared__ float s_tile[4];
   __shared__ double s_sum[256];
   const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4;
-  const long n_dir = (long)tiles_x * tiles_y * B, n_tiles = 2 * n_dir;
+  const long n_dir = (long)tiles_x * tiles_y * B;                 // tiles per direction
+  const long units_dir = (n_dir + kGeoGroup - 1) / kGeoGroup, n_units = 2 * units_dir;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // a WAVEFRONT per tile, lane <-> column, the tile's four rows in the lane's registers (four independent chains of
-  // dependent loads in flight instead of one): row sums by shuffle, then row 0 + 1 + 2 + 3 -- the order block_partial
-  // adds its four wavefronts in
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long)gridDim.x * 4) {
-    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y), z = (int)(tile / ((long)tiles_x * tiles_y));
-    const int w = tx * 64 + lane;
-    const bool rev = z >= B;
-    const int b = rev ? z - B : z;
-    const long plane = (long)b * H * W;
-    const Pose P = rev ? load_pose(K, R1, t1, R0, t0, b) : load_pose(K, R0, t0, R1, t1, b);
-    const float* da = rev ? depth1 : depth0;
-    const float* db = rev ? depth0 : depth1;
-    float term[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int h = ty * 4 + k;
-      term[k] = 0.f;
-      if (w < W && h < H) {
-        const long q = (long)h * W + w;
-        const GeoPoint g = geo_forward(P, ray + q * 3, da[plane + q], db + plane, H, W);
-        term[k] = clamp > 0.f ? fminf(g.diff, clamp) : g.diff;
-      }
-    }
+  for (long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const bool rev = unit >= units_dir;
+    const long t_dir = (unit - (rev ? units_dir : 0)) * kGeoGroup + wave;     // this wavefront's tile within the direction
     float t = 0.f;
+    if (t_dir < n_dir) {                                          // (wave-uniform)
+      // lane <-> column, the tile's four rows in the lane's registers (four independent chains of dependent loads in
+      // flight): row sums by shuffle, then row 0 + 1 + 2 + 3 -- the order block_partial adds its four wavefronts in
+      const int tx = (int)(t_dir % tiles_x), ty = (int)((t_dir / tiles_x) % tiles_y), b = (int)(t_dir / ((long)tiles_x * tiles_y));
+      const int w = tx * 64 + lane;
+      const long plane = (long)b * H * W;
+      const Pose P = rev ? load_pose(K, R1, t1, R0, t0, b) : load_pose(K, R0, t0, R1, t1, b);
+      const float* da = rev ? depth1 : depth0;
+      const float* db = rev ? depth0 : depth1;
+      float term[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t += wave_sum(term[k]);
-    if (lane == 0) __hip_atomic_store(partials + tile, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < 4; ++k) {
+        const int h = ty * 4 + k;
+        term[k] = 0.f;
+        if (w < W && h < H) {
+          const long q = (long)h * W + w;
+          const GeoPoint g = geo_forward(P, ray + q * 3, da[plane + q], db + plane, H, W);
+          term[k] = clamp > 0.f ? fminf(g.diff, clamp) : g.diff;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t += wave_sum(term[k]);
+    }
+    if (lane == 0) s_tile[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double q = 0;
+      for (int k = 0; k < kGeoGroup; ++k)
+        if ((unit - (rev ? units_dir : 0)) * kGeoGroup + k < n_dir) q += (double)s_tile[k];
+      __hip_atomic_store(unit_sums + unit, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's partials have been written where all XCDs see them
-  __syncthreads();
   if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the unit sums have been written where all XCDs see them
     const unsigned group = blockIdx.x % kGeoSymGroups;
     const unsigned in_group = (gridDim.x - group + kGeoSymGroups - 1) / kGeoSymGroups;
     bool last = __hip_atomic_fetch_add(ticket + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1u;
@@ -392,23 +418,22 @@ __global__ __launch_bounds__(256) void geometric_sym_fwd_kernel(const float* __r
     s_last = last;
   }
   __syncthreads();
-  if (!s_last) return;                             // (workgroup-uniform)
-  // acquire side: invalidate what this CU / XCD may hold of the partials' lines (no write-back involved), then plain
-  // loads -- as device-scope atomic loads the 54 per thread went out one round trip at a time (42 us for the launch)
+  if (!s_last) return;                                            // (workgroup-uniform)
+  // acquire side: invalidate what this CU / XCD may hold of the sums' lines (no write-back involved), then plain loads
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   float v[2];
   for (int dir = 0; dir < 2; ++dir) {
     double t = 0;
-    const float* pd = partials + dir * n_dir;
+    const double* pd = unit_sums + dir * units_dir;
     long i = threadIdx.x;
-    for (; i + 7 * 256 < n_dir; i += 8 * 256) {      // eight independent loads in flight, added in index order
-      float x[8];
+    for (; i + 7 * 256 < units_dir; i += 8 * 256) {                // eight independent loads in flight, added in index order
+      double x[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) x[k] = pd[i + k * 256];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += (double)x[k];
+      for (int k = 0; k < 8; ++k) t += x[k];
     }
-    for (; i < n_dir; i += 256) t += (double)pd[i];
+    for (; i < units_dir; i += 256) t += pd[i];
     s_sum[threadIdx.x] = t;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -494,7 +519,7 @@ int geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray
                      clamp);
   CTD_LAUNCH_CHECK();
   hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, loss_grid_blocks(B, H, W),
-                     (double)B * H * W, loss, accumulate);
+                     (double)B * H * W, loss, accumulate, kGeoGroup);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }
@@ -502,10 +527,12 @@ int geometric_fwd_f32(const float* depth0, const float* depth1, const float* ray
 int geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float* ray, const float* K, const float* R0,
                           const float* t0, const float* R1, const float* t1, float* loss, int B, int H, int W, float clamp,
                           void* ws, size_t ws_bytes, unsigned* ticket, hipStream_t s) {
-  if (!ws || ws_bytes < geometric_workspace_bytes(2 * B, H, W) || !ticket) return CTD_ERR_WORKSPACE;
-  const long n_tiles = (long)ceil_div(W, 64) * ceil_div(H, 4) * 2 * B;
-  dim3 grid((unsigned)(n_tiles < kGeoSymBlocks ? n_tiles : kGeoSymBlocks)), block(256);
-  hipLaunchKernelGGL(geometric_sym_fwd_kernel, grid, block, 0, s, depth0, depth1, ray, K, R0, t0, R1, t1, (float*)ws, ticket,
+  // (one f64 per unit of four tiles: 2 x ceil(n_dir / 4) x 8 bytes <= the 2 x n_dir x 4 bytes of the tiles' f32 partials + 64)
+  if (!ws || ws_bytes < geometric_workspace_bytes(2 * B, H, W) || ((uintptr_t)ws & 7) || !ticket) return CTD_ERR_WORKSPACE;
+  const long n_dir = (long)ceil_div(W, 64) * ceil_div(H, 4) * B;
+  const long n_units = 2 * ((n_dir + kGeoGroup - 1) / kGeoGroup);
+  dim3 grid((unsigned)(n_units < kGeoSymBlocks ? n_units : kGeoSymBlocks)), block(256);
+  hipLaunchKernelGGL(geometric_sym_fwd_kernel, grid, block, 0, s, depth0, depth1, ray, K, R0, t0, R1, t1, (double*)ws, ticket,
                      loss, B, H, W, clamp, (double)B * H * W);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
