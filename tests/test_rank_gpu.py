@@ -231,6 +231,26 @@ def test_prepared_pattern_shapes(te, N, H, W, D):
         assert torch.equal(te.xcorrvol_batch(A, B, D, 9, algo="fast", prepared=h), want[2])
 
 
+@pytest.mark.parametrize("W,bs", [(261, 9), (258, 5), (67, 7)])
+def test_workspace_contents_do_not_matter_fallback_kernels(te, W, bs):
+    """the same for widths off the 4-column grid and the small block sizes (wide / narrow fallback kernels)"""
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    N, H, D = 2, 30, 37
+    rs = np.random.RandomState(W + bs)
+    A = dev(rs.randn(N, 1, H, W).astype(np.float32)); B = dev(rs.randn(1, H, W).astype(np.float32))
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fill in (0x00, 0xFF):
+        vol = torch.empty((N, D, H, W), device="cuda")
+        ws = torch.full((L.ctd_xcorrvol_workspace_bytes(N, 1, H, W, D, bs, 1),), fill, dtype=torch.uint8, device="cuda")
+        assert L.ctd_xcorrvol_f32(A.data_ptr(), B.data_ptr(), 0, vol.data_ptr(), N, 1, H, W, D, bs, 1, ws.data_ptr(), ws.numel(), 0, s) == 0
+        outs.append(vol)
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[1]).all())
+    ve = te.xcorrvol_batch(A, B, D, bs, algo="exact")
+    assert bool(((outs[1] - ve).abs() <= ve.abs() * 1e-5 + 1e-6).all())
+
+
 @pytest.mark.parametrize("C", [1, 2])
 def test_workspace_contents_do_not_matter(te, C):
     """the planes of the pre-pass have columns nobody computes (halo columns of the statistics planes, alignment padding):
