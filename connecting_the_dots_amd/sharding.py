@@ -26,14 +26,60 @@ def check_gpu_count(n_ranks, backend, n_devices, what="--gpus"):
     return None
 
 
+def _parse_visible(value, total):
+    """Number of devices a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES style list leaves of `total` (the runtime stops
+    at the first entry it cannot resolve; UUID entries are counted as given)."""
+    n = 0
+    for tok in value.split(","):
+        tok = tok.strip()
+        if not tok:
+            break
+        if tok.lstrip("-").isdigit():
+            if not 0 <= int(tok) < total:
+                break
+        n += 1
+    return n
+
+
+def visible_gpu_count(kfd_nodes="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process tree would see, WITHOUT loading the HIP runtime: the launcher parent stays a process that never
+    touched a GPU.  (`torch.cuda.device_count()` falls back to `hipGetDeviceCount` whenever amdsmi cannot be imported,
+    which initialises the runtime in the caller.)  KFD topology nodes with a non-zero `simd_count` are the GPUs (CPU
+    nodes report 0); ROCR_VISIBLE_DEVICES, then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES, narrow the list the way the
+    runtime applies them.  Returns -1 when the topology cannot be read (no driver: the caller decides)."""
+    try:
+        nodes = sorted(os.listdir(kfd_nodes), key=lambda s: int(s) if s.isdigit() else 1 << 30)
+    except OSError:
+        return -1
+    total = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(kfd_nodes, node, "properties")) as fh:
+                props = dict(line.split(None, 1) for line in fh if len(line.split(None, 1)) == 2)
+        except OSError:
+            continue                                    # a node of another container's cgroup: not ours to use
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            total += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in os.environ:
+            total = _parse_visible(os.environ[var], total)
+            if var != "ROCR_VISIBLE_DEVICES":
+                break                                   # HIP_ and CUDA_VISIBLE_DEVICES are one setting (HIP's wins)
+    return total
+
+
 def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
-    """Start `n_ranks` fresh interpreters of `script` (one process per GPU; the caller has not touched a GPU and never
-    re-execs), rendezvous on 127.0.0.1, relay rank 0's stdout, return an exit code.  A rank that dies takes the others
-    down with it, and the whole launch has a deadline (CTD_BENCH_DEADLINE_S, default 900 s): no wedged rank keeps the
-    parent waiting."""
+    """Start `n_ranks` fresh interpreters of `script` (one process per GPU; this parent does not load the HIP runtime
+    -- it counts GPUs from the KFD topology -- and never re-execs), rendezvous on 127.0.0.1, relay rank 0's stdout while
+    the ranks run, return an exit code.  A rank that dies takes the others down with it, and the whole launch has a
+    deadline (CTD_BENCH_DEADLINE_S, default 900 s): no wedged rank keeps the parent waiting."""
     import socket
+    import threading
     backend = os.environ.get("CTD_DIST_BACKEND", "nccl")
-    err = check_gpu_count(n_ranks, backend, torch.cuda.device_count())      # (counting devices does not initialise HIP)
+    n_dev = visible_gpu_count()
+    if n_dev < 0:                                       # no KFD topology to read (not a ROCm host): ask the runtime
+        n_dev = torch.cuda.device_count()
+    err = check_gpu_count(n_ranks, backend, n_dev)
     if err:
         sys.stderr.write("%s: %s\n" % (os.path.basename(script), err))
         return 2
@@ -52,6 +98,18 @@ def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
                                       stdout=(subprocess.PIPE if capture_rank0 else None) if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained while the ranks run: a rank that prints more than a pipe buffer (verbose RCCL logs)
+    # would otherwise block in write() until the deadline
+    chunks = []
+
+    def _drain(fh):
+        for block in iter(lambda: fh.read(65536), b""):
+            chunks.append(block)
+
+    reader = None
+    if procs[0].stdout is not None:
+        reader = threading.Thread(target=_drain, args=(procs[0].stdout,), daemon=True)
+        reader.start()
     t_end = time.monotonic() + deadline_s
     failed = None
     while True:
@@ -72,9 +130,11 @@ def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
                     p.kill()
             break
         time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else b""
     for p in procs:
         p.wait()
+    if reader is not None:
+        reader.join(timeout=10)
+    out = b"".join(chunks)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     if failed:
@@ -117,15 +177,23 @@ def reduce_ratio_ddp(numerator, denominator, group=None):
     single-process batch.  Value: the global ratio on every rank (what the reference logs); the denominator carries
     no gradient (in the reference it is the LCN std of the input, or a sample count)."""
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
-        return numerator.reshape(()) / denominator.reshape(())
+        d1 = denominator.reshape(()).detach()
+        return numerator.reshape(()) * torch.where(d1 > 0, 1.0 / torch.where(d1 > 0, d1, torch.ones_like(d1)),
+                                                   torch.zeros_like(d1))
     world = dist.get_world_size(group)
     local = torch.stack([numerator.reshape(()), denominator.reshape(())]).detach()
     total = local.clone()
     dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     total = total.to(numerator.device)
-    den = total[1].clamp_min(torch.finfo(total.dtype).tiny)
-    grad_path = numerator.reshape(()) * (float(world) / den)
-    return grad_path + (total[0] / den - grad_path.detach())
+    # A global denominator of 0 (no supervised sample on any rank: the reference supervises only the last 256 ids,
+    # exp_synph.py:39) is a term of value 0 and gradient 0 -- never `world / tiny`, which is inf in f32 from world = 4
+    # and turns the zero numerator into NaN.
+    ok = total[1] > 0
+    den = torch.where(ok, total[1], torch.ones_like(total[1]))
+    scale = torch.where(ok, float(world) / den, torch.zeros_like(den))
+    grad_path = numerator.reshape(()) * scale
+    value = torch.where(ok, total[0] / den, torch.zeros_like(den))
+    return grad_path + (value - grad_path.detach())
 
 
 def reduce_mean(value, count, group=None):

@@ -70,3 +70,98 @@ def test_frame_shard_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_zero_den(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from connecting_the_dots_amd import sharding
+    # the edge term of a config-5 step without a supervised sample on ANY rank (exp_synph.py:39 supervises the last 256
+    # ids only): numerator 0 * something, count 0 -- value and gradient must be 0, not NaN (f32: world / tiny = inf
+    # from world = 4)
+    w = torch.ones(3, dtype=torch.float32, requires_grad=True)
+    num = (w * 0.0).sum()
+    cnt = torch.zeros((), dtype=torch.float32)
+    val = sharding.reduce_ratio_ddp(num, cnt)
+    val.backward()
+    # and an ordinary step right after: one rank has samples, the others none
+    w2 = torch.ones(3, dtype=torch.float32, requires_grad=True)
+    num2 = (w2 * float(rank == 1)).sum()
+    cnt2 = torch.tensor(3.0 if rank == 1 else 0.0)
+    val2 = sharding.reduce_ratio_ddp(num2, cnt2)
+    val2.backward()
+    q.put((rank, float(val), w.grad.tolist(), float(val2), w2.grad.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ratio_ddp_zero_global_denominator_world4():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 4
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_zero_den, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, v, g, v2, g2 in res:
+        assert v == 0.0 and g == [0.0, 0.0, 0.0]                          # finite zeros, no NaN
+        assert abs(v2 - 1.0) < 1e-6                                       # 3 / 3 on every rank
+        # DDP averages: world * d num_r / DEN -> 4/3 per element on the rank that has the samples, 0 elsewhere
+        assert all(abs(x - (4.0 / 3.0 if rank == 1 else 0.0)) < 1e-6 for x in g2)
+
+
+def test_ratio_ddp_single_process_zero_denominator():
+    from connecting_the_dots_amd import sharding
+    w = torch.ones(2, requires_grad=True)
+    v = sharding.reduce_ratio_ddp((w * 0.0).sum(), torch.zeros(()))
+    v.backward()
+    assert float(v.detach()) == 0.0 and w.grad.tolist() == [0.0, 0.0]
+
+
+def test_visible_gpu_count_reads_kfd_without_the_runtime(tmp_path, monkeypatch):
+    from connecting_the_dots_amd import sharding
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):                   # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\n" % (64 if simd == 0 else 0, simd))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert sharding.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert sharding.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,7,0")                    # the runtime stops at the first bad entry
+    assert sharding.visible_gpu_count(str(tmp_path)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert sharding.visible_gpu_count(str(tmp_path)) == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0")
+    assert sharding.visible_gpu_count(str(tmp_path)) == 1
+    assert sharding.visible_gpu_count(str(tmp_path / "missing")) == -1
+
+
+def test_launch_ranks_drains_a_chatty_rank0(tmp_path):
+    """rank 0 printing far more than a pipe buffer must not block until the deadline."""
+    from connecting_the_dots_amd import sharding
+    script = tmp_path / "chatty.py"
+    script.write_text("import os, sys\n"
+                      "if os.environ['RANK'] == '0':\n"
+                      "    sys.stdout.write('x' * (1 << 20)); sys.stdout.write('\\nDONE\\n')\n")
+    import io
+    import contextlib
+    import time
+    os.environ["CTD_DIST_BACKEND"] = "gloo"
+    try:
+        buf = io.StringIO()
+        t0 = time.time()
+        with contextlib.redirect_stdout(buf):
+            rc = sharding.launch_ranks(str(script), [], 2, deadline_s=60)
+        assert rc == 0 and time.time() - t0 < 30
+        assert buf.getvalue().endswith("DONE\n") and len(buf.getvalue()) > (1 << 20)
+    finally:
+        os.environ.pop("CTD_DIST_BACKEND", None)
