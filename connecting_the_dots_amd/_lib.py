@@ -23,8 +23,6 @@ _levels_p = ctypes.POINTER(PatternLevel)
 SIGNATURES = {
     "ctd_version": (_c_int, []),
     "ctd_status_string": (ctypes.c_char_p, [_c_int]),
-    "ctd_kernel_timing_enable": (None, [_c_int]),
-    "ctd_kernel_timing_collect": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
     "ctd_xcorrvol_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_xcorrvol_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 7 + [_vp, _c_size_t, _c_int, _vp]),
     "ctd_xcorrvol_pattern_prepare_f32": (_c_int, [_vp, _c_long] + [_c_int] * 6 + [_vp, _c_size_t, _c_int, _vp]),
@@ -71,6 +69,12 @@ SIGNATURES = {
     "ctd_proj_nn_f64": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_vp, _c_int, _vp]),
 }
 
+# measurement hooks of include/ctd_hip_bench.h (bench.py, tools/): not part of the drop-in interface
+BENCH_SIGNATURES = {
+    "ctd_kernel_timing_enable": (None, [_c_int]),
+    "ctd_kernel_timing_collect": (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_int)]),
+}
+
 _lib = None
 
 
@@ -83,7 +87,7 @@ def lib():
                 "connecting_the_dots_amd: %s is missing -- build it with "
                 "`python -m connecting_the_dots_amd.build` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
         l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(BENCH_SIGNATURES.items()):
             fn = getattr(l, name)       # AttributeError here means header / library mismatch
             fn.restype = res
             fn.argtypes = args

@@ -32,7 +32,7 @@ def sources():
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + [HEADER]
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(os.path.dirname(HEADER), "*.h"))
 
 
 def _obj(src):

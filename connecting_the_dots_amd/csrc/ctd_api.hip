@@ -1,6 +1,7 @@
 // ctd_api.hip -- the extern "C" surface declared in include/ctd_hip.h.
 // Argument validation lives here; kernels assume validated shapes.
 #include "ctd_internal.h"
+#include "../../include/ctd_hip_bench.h"
 
 #include <deque>
 #include <utility>
@@ -9,15 +10,17 @@
 using namespace ctd;
 
 namespace ctd {
-// Bench instrumentation (ctd_kernel_timing_*): process-global, one bench thread (documented in the header).
+// Bench instrumentation (include/ctd_hip_bench.h, ctd_kernel_timing_*): NOT part of the drop-in ABI of
+// include/ctd_hip.h.  The state is per calling thread (thread_local): the thread that enables it sees its own launches
+// only, other threads of the process launch un-instrumented and race with nothing.
 // The events come from a pool created when timing is switched on (no hipEventCreate between launches) and carry
 // hipEventDisableSystemFence: a default event makes the queue release to system scope at every record (an L2
 // write-back of whatever the previous kernel left dirty), which the un-instrumented path never pays.
-static bool g_timing = false;
-static int g_timing_columns = 0;
-static std::deque<hipEvent_t> g_pool;                                    // free events, reused first-in first-out
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;          // recorded (start, stop) pairs
-static hipEvent_t g_pending = nullptr;
+static thread_local bool g_timing = false;
+static thread_local int g_timing_columns = 0;
+static thread_local std::deque<hipEvent_t> g_pool;                                    // free events, reused first-in first-out
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;          // recorded (start, stop) pairs
+static thread_local hipEvent_t g_pending = nullptr;
 static hipEvent_t pool_get() {
   if (!g_pool.empty()) {
     hipEvent_t e = g_pool.front();

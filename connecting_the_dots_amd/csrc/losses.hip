@@ -351,6 +351,21 @@ __global__ __launch_bounds__(256) void geometric_fwd_kernel(const float* __restr
 // words, then one global word -- because 13 824 device-scope increments of ONE word took 176 us (~12 ns apiece,
 // serialised).  Units of four tiles instead of single tiles: a quarter of the values for the last workgroup to read.
 // As two launches + two one-workgroup reductions the pair cost 2 x 12.3 + 2 x 8.6 us of the config-3 step.
+//
+// Memory-model note.  This is NOT a C++ release / acquire pair: the ticket increments are relaxed.  It is the hand-off
+// form MI355X_MICROARCH.md lists as valid on gfx950 ("Valid forms": write-through `sc1` payload stores by ONE lane of
+// the storing workgroup -> that lane's `s_waitcnt vmcnt(0)` -> its agent-scope atomic add; the workgroup whose add came
+// last learns it from the returned value, passes it through a workgroup barrier, and reads behind an agent-scope
+// acquire): the payload has reached the memory side before the add is issued because the same lane waited for it, and
+// the inline asm wait is invisible to the compiler pass that drops redundant waits.  That is a property of gfx950's
+// sc1 stores, not of the language, hence the guard below: any other target must take the two-call path
+// (ctd_geometric_fwd_f32 twice), which needs no cross-workgroup visibility inside a launch.  A release on the
+// increments instead (buffer_wbl2 per workgroup) was measured at 260 us for this launch against 34.
+// The host side clears the ticket words whenever this call returns an error (geometric_sym_fwd_f32 below and the
+// Python wrapper): a dirty word would leave every later launch on them without a last workgroup.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "geometric_sym_fwd_kernel's hand-off relies on gfx950 sc1 write-through stores: build for gfx950 only"
+#endif
 constexpr int kGeoSymBlocks = 4096, kGeoSymGroups = 64;      // ticket words: [0] global, [1 .. kGeoSymGroups] groups
 
 __global__ __launch_bounds__(256) void geometric_sym_fwd_kernel(const float* __restrict__ depth0,
@@ -534,7 +549,12 @@ int geometric_sym_fwd_f32(const float* depth0, const float* depth1, const float*
   dim3 grid((unsigned)(n_units < kGeoSymBlocks ? n_units : kGeoSymBlocks)), block(256);
   hipLaunchKernelGGL(geometric_sym_fwd_kernel, grid, block, 0, s, depth0, depth1, ray, K, R0, t0, R1, t1, (double*)ws, ticket,
                      loss, B, H, W, clamp, (double)B * H * W);
-  CTD_LAUNCH_CHECK();
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    // whatever state the words are in, the next call must find them at zero (stream-ordered behind anything queued)
+    (void)hipMemsetAsync(ticket, 0, sizeof(unsigned) * (kGeoSymGroups + 1), s);
+    return CTD_ERR_HIP + (int)e;
+  }
   return CTD_OK;
 }
 

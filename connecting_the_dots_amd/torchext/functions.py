@@ -78,6 +78,17 @@ def _ticket(dev):
     return t
 
 
+def _call_with_ticket(call, ticket, what):
+    """Runs `call(ticket)` (a C-ABI launch that takes its ticket words at zero and leaves them at zero).  When it
+    returns an error the words may be anywhere in between -- a later launch on them would then have no "last"
+    workgroup and leave its result unwritten -- so they are cleared (stream-ordered, like the launch) before the error
+    is raised."""
+    st = call(ticket)
+    if st != 0:
+        ticket.zero_()
+    _lib.check(st, what)
+
+
 # --------------------------------------------------------------------------------------
 # Nearest-neighbour consistency ops (reference: NNFunction / CrossCheckFunction / ProjNNFunction,
 # functions.py:5-56; bindings ext_cuda.cpp:17-68)
@@ -746,10 +757,9 @@ class GeometricLossFunction(torch.autograd.Function):
         if L.ctd_geometric_workspace_bytes(2 * B, H, W) > 0:
             # both directions in one launch, the means formed by its last workgroup (tickets: zeroed words per stream)
             ws = _workspace(L.ctd_geometric_workspace_bytes(2 * B, H, W), dev)
-            st = L.ctd_geometric_sym_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1),
-                                             _ptr(t1), _ptr(loss), B, H, W, c, _ptr(ws), ws.numel(), _ptr(_ticket(dev)),
-                                             dev.index, _stream(dev))
-            _lib.check(st, "geometric_loss")
+            _call_with_ticket(lambda tk: L.ctd_geometric_sym_fwd_f32(
+                _ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1), _ptr(loss), B, H, W,
+                c, _ptr(ws), ws.numel(), _ptr(tk), dev.index, _stream(dev)), _ticket(dev), "geometric_loss")
         else:
             ws = _workspace(L.ctd_geometric_workspace_bytes(B, H, W), dev)
             st = L.ctd_geometric_fwd_f32(_ptr(depth0), _ptr(depth1), _ptr(ray), _ptr(K), _ptr(R0), _ptr(t0), _ptr(R1), _ptr(t1),

@@ -41,21 +41,8 @@ enum ctd_status {
 int ctd_version(void);                       /* ABI version, currently 3 (2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
 const char* ctd_status_string(int status);
 
-/* --------------------------------------------------------------------------------------
- * Per-kernel device timing for benchmarks (off by default, zero cost when off).
- * When enabled, every launch of the dominant kernel of ctd_xcorrvol_f32 /
- * ctd_xcorrvol_argmax_f32 (the NCC volume kernel proper, not its pre-pass) is bracketed by
- * a pair of hipEvents recorded on the launch stream.  ctd_kernel_timing_collect()
- * synchronises those events, returns the number of launches seen since the last collect
- * and their average duration in milliseconds, and releases the events.
- * `columns` receives the number of output columns per row that kernel covers (the
- * remaining W - columns are produced by a secondary kernel), so that the caller can
- * price the launch in algorithmic bytes.  Not thread-safe; meant for one bench process.
- * `enable` > 1 also says how many events to hold ready (two per launch until the next
- * collect; 128 by default): none is created or first recorded between two launches then.
- * -------------------------------------------------------------------------------------- */
-void ctd_kernel_timing_enable(int enable);
-int ctd_kernel_timing_collect(double* avg_ms, int* columns);
+/* (Bench instrumentation -- per-kernel device timing of the volume kernel -- is declared in ctd_hip_bench.h: it is not
+ * part of the drop-in interface.) */
 
 /* photometric loss types -- torchext/ext/ext.h:196-199, torchext/functions.py:106-118 */
 #define CTD_PHOTOMETRIC_MSE 0

@@ -10,10 +10,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ctd_hip.h")
+BENCH_HEADER = os.path.join(ROOT, "include", "ctd_hip_bench.h")
 
 
-def declared_symbols():
-    src = open(HEADER).read()
+def declared_symbols(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ctd_[a-z0-9_]+)\s*\(", src)))
 
@@ -23,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     from connecting_the_dots_amd import build
     build.build()
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    names = declared_symbols()
+    names = declared_symbols() + declared_symbols(BENCH_HEADER)
     assert len(names) >= 12
     for n in names:
         assert hasattr(lib, n), "libctd_hip.so does not export %s" % n
@@ -32,6 +33,9 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from connecting_the_dots_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
+    # the measurement hooks live in a header of their own, outside the drop-in interface
+    assert sorted(_lib.BENCH_SIGNATURES) == declared_symbols(BENCH_HEADER)
+    assert not any("timing" in n for n in declared_symbols())
     assert _lib.lib().ctd_version() == 3
     assert _lib.lib().ctd_status_string(1) == b"invalid argument"
 
@@ -112,3 +116,33 @@ def test_all_d_plan_of_the_benchmark_shapes():
     assert L.ctd_xcorrvol_rank_supported(1, 432, 512, 600, 9) == 0      # D > 512
     need = L.ctd_xcorrvol_argmax_workspace_bytes(16, 1, 432, 512, 128, 9, 1)
     assert need >= L.ctd_xcorrvol_workspace_bytes(16, 1, 432, 512, 128, 9, 1) > 0
+
+
+def test_ticket_words_are_cleared_when_a_launch_returns_an_error():
+    """A launch that takes its ticket words at zero and fails must not leave them dirty for the next call."""
+    from connecting_the_dots_amd.torchext import functions as F
+    ticket = torch.zeros(128, dtype=torch.int32)
+
+    def failing(tk):
+        tk[3] = 7                                            # what an aborted launch may leave behind
+        return 2                                             # CTD_ERR_WORKSPACE
+    with pytest.raises(RuntimeError, match="workspace"):
+        F._call_with_ticket(failing, ticket, "geometric_loss")
+    assert int(ticket.abs().sum()) == 0
+    F._call_with_ticket(lambda tk: 0, ticket, "geometric_loss")   # a good call passes straight through
+
+
+def test_kernel_timing_state_is_per_thread():
+    """The measurement hooks keep their state per calling thread: enabling them in one thread does not instrument (or
+    race with) launches of another.  Without a GPU: collect() in a thread that never enabled them reports nothing."""
+    import threading
+    from connecting_the_dots_amd import _lib
+    L = _lib.lib()
+    seen = {}
+
+    def other():
+        seen["n"] = L.ctd_kernel_timing_collect(None, None)
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen["n"] == 0
