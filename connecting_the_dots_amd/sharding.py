@@ -212,14 +212,15 @@ def gather_scalars(value, group=None):
     return v
 
 
-def gather_scalars_async(value, out=None, group=None):
+def gather_scalars_async(value, out=None, group=None, force=False):
     """The same exchange without stalling the compute stream: the all-gather is queued on the collective's own stream
     behind `value` and the caller's stream does not wait for it.  Returns (out [world], work); `work` is None when
     there is nothing to exchange.  Keep `out` alive and call `work.wait()` (a stream-level wait on RCCL, no host block)
     before reading or reusing it -- in a steady loop that is one or more steps later, when the exchange has long
-    finished, so the 4 bytes per rank and the skew between ranks never sit on the step's critical path."""
+    finished, so the 4 bytes per rank and the skew between ranks never sit on the step's critical path.
+    `force`: go through the collective even in a one-rank group (the RCCL rehearsal on a one-GPU box)."""
     v = value.detach().reshape(1).contiguous()
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_initialized() and (force or dist.get_world_size(group) > 1)):
         return v, None
     world = dist.get_world_size(group)
     if out is None:

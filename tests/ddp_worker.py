@@ -16,8 +16,11 @@ def main():
     out_dir = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    if os.environ.get("CTD_DDP_BACKEND", "gloo") == "nccl":             # RCCL (tests/test_rccl_one_rank_gpu.py: one rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from connecting_the_dots_amd.train import TrackTrainer
     net, pats, K, batch = make_setup()
     tr = TrackTrainer(net, pats, K, 0.075, [567.6 / 4 / 2 ** s for s in range(4)], train_edge=0,
