@@ -1503,7 +1503,6 @@ static_assert(kAA + kADGMax - 1 < kASpanPad, "pattern span must fit its padded a
 constexpr int kAHalo = kAWaves * 2 * 2 * 4;    // [wave][j][side][4] halo sums
 constexpr int kAPack = 3 * kAA + 3 * kASpanPad + kAHalo;   // 1920 floats per staged row
 constexpr int kABufs = 3;                     // LDS chunks in the ring; a chunk is ROWS = 3 or 2 staged rows (template parameter)
-constexpr int kADmaPerRow = 12;                // 3 x 2 frame-side + 3 x 2 pattern-side dwordx4 DMAs
 constexpr int kAOffB = 3 * kAA, kAOffH = 3 * kAA + 3 * kASpanPad;
 // band height limit: rank slots (2 KB per row) + staging ring <= 160 KB -- 44 rows with 3-row chunks, 57 with 2-row chunks
 constexpr int alld_max_band_rows(int rows) { return (160 * 1024 - (int)sizeof(float) * kABufs * rows * kAPack) / 2048; }
@@ -1523,10 +1522,43 @@ __device__ inline unsigned umed3(unsigned a, unsigned b, unsigned c) {
 // fixed-point units of the keys per unit of score, and the re-ranking margin in those units (ctd_rank.h: rank_margin)
 __device__ inline unsigned key_margin_units(float eps) { return (unsigned)ceilf(rank_margin(eps, 1.f) * 2097152.f); }
 
-template <int MODE, int KS, int ROWS>
+// Diagnostic build only (-DCTD_STAMPS, tools/build_variant.sh): every wavefront of the all-D kernel notes the shader
+// clock (s_memtime) when it ARRIVES at each chunk barrier of pass CTD_STAMP_PASS and when it LEAVES it, into LDS behind
+// the staging ring; the workgroup dumps them at its end ([workgroup][kStampWords]: 8 header words, then
+// [wave][chunk][arrive | leave]).  tools/alld_timeline.py reads them through ctd_debug_read_stamps.  No stamp executes
+// in the product build.
+#ifdef CTD_STAMPS
+#ifndef CTD_STAMP_PASS
+#define CTD_STAMP_PASS 2
+#endif
+constexpr int kStampChunks = 34, kStampWords = 8 + 16 * kStampChunks * 2, kStampWgs = 1024;
+__device__ unsigned g_stamps[kStampWgs * kStampWords];
+__device__ inline unsigned stamp_now() { return (unsigned)__builtin_amdgcn_s_memtime(); }
+// (no scalar of its own: the consumer loops are at the limit of the scalar registers -- hipcc 7.2 dies with "illegal VGPR
+// to SGPR copy" when their spilling fails -- so the wavefront number comes from threadIdx and the stamp area's address is
+// an immediate offset from the ring's base)
+__device__ inline void stamp_put(unsigned* st, int pass, int chunk, int which) {
+  const unsigned t = stamp_now();
+  const int idx = 8 + ((int)(threadIdx.x >> 6) * kStampChunks + chunk) * 2 + which;
+  if ((threadIdx.x & 63) == 0 && pass == CTD_STAMP_PASS && chunk < kStampChunks) st[idx] = t;
+}
+#define CTD_STAMP_ARRIVE(st, wave, pass, chunk, lane) stamp_put(st, pass, chunk, 0)
+#define CTD_STAMP_LEAVE(st, wave, pass, chunk, lane) stamp_put(st, pass, chunk, 1)
+#else
+#define CTD_STAMP_ARRIVE(st, wave, pass, chunk, lane) do {} while (0)
+#define CTD_STAMP_LEAVE(st, wave, pass, chunk, lane) do {} while (0)
+#endif
+
+// JM: which of the pair's two disparities this wavefront works on -- 3 = both (the regular consumer), 1 = j 0 only,
+// 2 = j 1 only: the two halves of a SPLIT pair, run by two wavefronts on different SIMDs (see the kernel: with 13 pairs
+// per pass the thirteenth pair would otherwise put a fourth full consumer on one SIMD and the chunk barrier makes
+// everybody wait for that SIMD).  WAVE is the PAIR index (span slots, halo slots, disparity base); `wave_id` the
+// wavefront's own number (diagnostic stamps only).
+template <int MODE, int KS, int ROWS, int JM = 3>
 __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, float* __restrict__ out, int WAVE, int f,
                                              int lane, int w_lo, int h_lo, int h_hi, int r_begin, int n_iters,
-                                             int n_pass, int rot, int dgs, int H, int W, int D) {
+                                             int n_pass, int rot, int dgs, int H, int W, int D, int wave_id) {
+  constexpr int J0 = (JM & 1) ? 0 : 1;                             // first active j
   constexpr int TAIL = 4, STEP = 6, CPI = STEP / ROWS;            // block size 9
   constexpr bool STORE = (MODE & kAStore) != 0, RANK = (MODE & kARank) != 0;
   static_assert(STEP % ROWS == 0, "a chunk never straddles two outer iterations");
@@ -1556,6 +1588,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
   // registers alive across the whole loop.
   unsigned rk_hi[4], rk_lo[4], rk_old[4];
   unsigned* rk_sl = rank_lds + lane;
+#define st_lds ((unsigned*)(lds + kABufs * ROWS * kAPack))
 #pragma unroll
   for (int i = 0; i < 4; ++i) rk_hi[i] = rk_lo[i] = rk_old[i] = 0u;
   auto rank_second = [&]() {
@@ -1571,11 +1604,13 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
   for (int pass = 0; pass < n_pass; ++pass) {
     const int grp = pass + rot >= n_pass ? pass + rot - n_pass : pass + rot;
     const int d_base = grp * dgs + WAVE * 2;
-    if (WAVE * 2 >= dgs || d_base >= D) {
+    if (WAVE * 2 >= dgs || d_base + J0 >= D) {
       // a wavefront without disparities in this pass (the pass is narrower than 15 pairs, or it is the last pass and
       // both disparities lie past D): keep the barrier protocol, skip the work
       for (int k = 0; k < n_iters * CPI; ++k) {
+        CTD_STAMP_ARRIVE(st_lds, wave_id, pass, k, lane);
         wg_barrier();
+        CTD_STAMP_LEAVE(st_lds, wave_id, pass, k, lane);
         slot = slot == kABufs - 1 ? 0 : slot + 1;
       }
       continue;
@@ -1626,6 +1661,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+            if (!(JM & (1 << j))) continue;
             float sP = P[j][i][(u + 1) % 2] + P[j][i][u % 2];
             float sT = T[j][i][(u + 3) % 6] + T[j][i][u % 6];
             asm("" : "+v"(sP), "+v"(sT));                          // (formed before the slots are reused)
@@ -1652,6 +1688,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
           unsigned key[2][4];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
+            if (!(JM & (1 << j))) continue;
             float pre[4], suf[4];
             pre[0] = x[j][0];
             pre[1] = pre[0] + x[j][1];
@@ -1663,7 +1700,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             suf[0] = suf[1] + x[j][0];
             float sj[4];
             window_combine4(suf, pre[3], pre, sj);                  // wave-edge lanes get 0 from the missing neighbour
-            if (j == 0) {
+            if (j == J0) {
               // statistics quads: pinned after the first window sums (data dependency keeps the wait here)
               asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
               asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
@@ -1684,9 +1721,22 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             }
             if (STORE && lane_out && d < D) {
               long ooff = (long)d * HW + (long)h * W;
+#if defined(CTD_STORE_AB) && CTD_STORE_AB == 1
+              // TIMING EXPERIMENT ONLY (wrong layout): a permutation of the volume's 1-KB pieces -- workgroup-major, then
+              // row, then disparity -- so that the 26 pieces a workgroup writes per row step are one contiguous run
+              ooff = ((((long)blockIdx.x * (h_hi - h_lo) + (h - h_lo)) * D + d) << 8) - ((long)f * D * HW + w_lo);
+#elif defined(CTD_STORE_AB) && CTD_STORE_AB == 2
+              // TIMING EXPERIMENT ONLY: chip-linear -- everything the 256 workgroups write in one row step is one window
+              ooff = ((((((long)pass * (h_hi - h_lo) + (h - h_lo)) * gridDim.x + blockIdx.x) * dgs + (d - grp * dgs)) %
+                       ((long)gridDim.x * (h_hi - h_lo) * D)) << 8) - ((long)f * D * HW + w_lo);
+#endif
               asm("" : "+s"(ooff));
               // written once, next read by another kernel after 1.8 GB more: non-temporal
+#if defined(CTD_STORE_AB) && CTD_STORE_AB == 3
+              *(f32x4*)(vol + ooff + l4) = f32x4{val[0], val[1], val[2], val[3]};     // TIMING EXPERIMENT: plain stores
+#else
               __builtin_nontemporal_store(f32x4{val[0], val[1], val[2], val[3]}, (f32x4*)(vol + ooff + l4));
+#endif
             }
             if constexpr (RANK) {
               if (d < D) {                                         // wave-uniform branch (a select would be 4 VALU slots)
@@ -1709,8 +1759,13 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             rk_sl = rank_lds + (it * STEP + u - 2 * TAIL) * 512 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              rk_hi[i] = max(key[0][i], key[1][i]);
-              rk_lo[i] = min(key[0][i], key[1][i]);
+              if (JM == 3) {
+                rk_hi[i] = max(key[0][i], key[1][i]);
+                rk_lo[i] = min(key[0][i], key[1][i]);
+              } else {
+                rk_hi[i] = key[J0][i];                             // one key per pixel and row: the loser of the exchange
+                rk_lo[i] = 0u;                                     // with the slot's top is min(old, key) = med3(old, key, 0)
+              }
               rk_old[i] = __hip_atomic_fetch_max(rk_sl + 64 * i, rk_hi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
@@ -1733,11 +1788,100 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             }
           }
           wait_lgkmcnt0();
+          // (not in the volume + ranking instantiation: with the stamps' scalars on top hipcc 7.2 fails to spill its
+          // scalar registers -- "illegal VGPR to SGPR copy"; the timeline is taken in the two other modes)
+          if constexpr (MODE != (kAStore | kARank)) CTD_STAMP_ARRIVE(st_lds, wave_id, pass, it * CPI + u / ROWS, lane);
           wg_barrier();
+          if constexpr (MODE != (kAStore | kARank)) CTD_STAMP_LEAVE(st_lds, wave_id, pass, it * CPI + u / ROWS, lane);
           slot = slot == kABufs - 1 ? 0 : slot + 1;
         }
       }
     }
+  }
+}
+
+#undef st_lds
+
+// What the statistics DMAs of a chunk need (either loader).
+struct AlldStatsArgs {
+  const float *m0i, *v0i, *m1i, *v1i;       // this frame's mean / reciprocal-deviation planes (frame side: column c at c + 4)
+  float* lds;                               // staging ring
+  int Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs;
+};
+constexpr int kAStatsPerRow = 8, kAValuesPerRow = 4;   // dwordx4 LDS-DMA instructions per staged row
+
+// statistics rows of chunk (pass ip, chunk ic) into ring slot `sl`
+template <int ROWS>
+__device__ __forceinline__ void alld_issue_stats(const AlldStatsArgs& a, int ip, int ic, int sl, int lane) {
+  constexpr int TAIL = 4;
+  const int aq0 = min(a.c_lo + 4 * lane, a.Wp - 8), aq1 = min(a.c_lo + 256 + 4 * lane, a.Wp - 8);
+  const bool a_tail = 256 + 4 * lane < kAA, s_tail = 256 + 4 * lane < kASpanPad;
+  float* buf = a.lds + sl * (ROWS * kAPack);
+  const int xb = a.c_lo - (ip * a.dgs + a.dgs - 1);               // unclamped pattern column of span slot 0
+  const int sq0 = min(xb + a.xoff + 4 * lane, a.W1 - 4), sq1 = min(xb + a.xoff + 256 + 4 * lane, a.W1 - 4);
+#pragma unroll
+  for (int s2 = 0; s2 < ROWS; ++s2) {
+    const int r = a.r_begin + ic * ROWS + s2;
+    // statistics of output row r - TAIL (rows of a mixed chunk that complete no output re-read a row the band needs anyway)
+    const int hs = clampi(r - TAIL, a.h_lo, a.h_hi - 1);
+    float* pk = buf + s2 * kAPack;
+    dma_quad(a.m0i + (long)hs * a.Wp + aq0, pk + kAA);
+    dma_quad(a.v0i + (long)hs * a.Wp + aq0, pk + 2 * kAA);
+    dma_quad(a.m1i + (long)hs * a.W1 + sq0, pk + kAOffB + kASpanPad);
+    dma_quad(a.v1i + (long)hs * a.W1 + sq0, pk + kAOffB + 2 * kASpanPad);
+    if (a_tail) {
+      dma_quad(a.m0i + (long)hs * a.Wp + aq1, pk + kAA + 256);
+      dma_quad(a.v0i + (long)hs * a.Wp + aq1, pk + 2 * kAA + 256);
+    }
+    if (s_tail) {
+      dma_quad(a.m1i + (long)hs * a.W1 + sq1, pk + kAOffB + kASpanPad + 256);
+      dma_quad(a.v1i + (long)hs * a.W1 + sq1, pk + kAOffB + 2 * kASpanPad + 256);
+    }
+  }
+}
+
+// a chunk is LIGHT when none of its rows completes an output row of the band (the 8 warm-up rows of a pass and the padding
+// behind the last output row): nobody reads statistics there, none are staged
+template <int ROWS>
+__device__ __forceinline__ bool alld_chunk_is_light(int ch, int n_out_rows) {
+  return ch * ROWS + ROWS - 1 < 8 || ch * ROWS >= 8 + n_out_rows;
+}
+
+// The second loader (a spare consumer wavefront, see the roles in the kernel): the statistics rows, two chunks ahead,
+// in step with the chunk barriers; before each barrier everything but the newest chunk has landed.
+template <int ROWS>
+__device__ __forceinline__ void alld_stats_loader(const AlldStatsArgs& a, int lane) {
+  constexpr int LS = ROWS * kAStatsPerRow;
+  static_assert(LS < 64, "in-flight DMA count must fit vmcnt");
+  __builtin_amdgcn_s_setprio(3);
+  const int total = a.n_pass * a.n_chunks, n_out_rows = a.h_hi - a.h_lo;
+  int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;
+  auto issue_next = [&]() {                                        // returns whether anything was issued
+    const bool light = alld_chunk_is_light<ROWS>(i_ch, n_out_rows);
+    if (!light) alld_issue_stats<ROWS>(a, i_pass, i_ch, i_slot, lane);
+    ++i_n;
+    i_slot = i_slot == kABufs - 1 ? 0 : i_slot + 1;
+    if (++i_ch == a.n_chunks) { i_ch = 0; ++i_pass; }
+    return !light;
+  };
+  issue_next();
+  if (issue_next()) wait_vmcnt<LS>(); else wait_vmcnt<0>();        // chunk 0 has landed
+  wg_barrier();
+  int c_pass = 0, c_ch = 0;                                        // the chunk the consumers are working on (stamps)
+  (void)c_pass;
+  for (int g = 0; g < total; ++g) {
+    if (i_n < total) {
+      if (issue_next()) wait_vmcnt<LS>(); else wait_vmcnt<0>();    // chunk g + 1 has landed
+    } else {
+      wait_vmcnt<0>();
+    }
+#ifdef CTD_STAMPS
+    unsigned* st_l = (unsigned*)(a.lds + kABufs * ROWS * kAPack);
+#endif
+    CTD_STAMP_ARRIVE(st_l, kAWaves - 1, c_pass, c_ch, lane);
+    wg_barrier();
+    CTD_STAMP_LEAVE(st_l, kAWaves - 1, c_pass, c_ch, lane);
+    if (++c_ch == a.n_chunks) { c_ch = 0; ++c_pass; }
   }
 }
 
@@ -1775,62 +1919,96 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   const int n_chunks = n_iters * CPI;                              // per pass; a multiple of CPI
   const int n_act = dgs / 2;                                       // consumer wavefronts with work
   const int rot = 0;                                               // first disparity group of this workgroup (pass p works on group (p + rot) % n_pass)
+#ifdef CTD_STAMPS
+  unsigned* const st_lds = (unsigned*)(lds + kABufs * ROWS * kAPack);
+  for (int k = threadIdx.x; k < kStampWords; k += 64 * (kAWaves + 1)) st_lds[k] = 0u;
+  if (threadIdx.x == 0) {
+    st_lds[0] = stamp_now();
+    st_lds[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    st_lds[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID, bits 0..3
+    st_lds[3] = (unsigned)n_chunks;
+  }
+  auto dump_stamps = [&]() {
+    wait_lgkmcnt0();
+    wg_barrier();
+    if (threadIdx.x == 0) {
+      st_lds[4] = stamp_now();
+      st_lds[5] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
+    wait_lgkmcnt0();
+    wg_barrier();
+    if ((int)blockIdx.x < kStampWgs)
+      for (int k = threadIdx.x; k < kStampWords; k += 64 * (kAWaves + 1)) g_stamps[blockIdx.x * kStampWords + k] = st_lds[k];
+  };
+#endif
 
   // every wavefront clears its share of the rank slots (key 0 = below every score)
   if constexpr (RANK)
     for (int k = threadIdx.x; k < band_rows * 128; k += 64 * (kAWaves + 1)) ((uint4*)rank_lds)[k] = make_uint4(0u, 0u, 0u, 0u);
   wait_lgkmcnt0();                                                 // (the consumers' first barrier is a raw s_barrier)
 
+  // ---- roles.  Pairs of disparities per pass: n_act = dgs / 2 (13 for D = 128).  The chunk barrier makes every
+  // wavefront wait for the slowest SIMD, and wavefront w sits on SIMD w % 4 (the timeline of the -DCTD_STAMPS build:
+  // profiles/round4_alld_timeline.txt), so the roles are dealt to even out the four SIMDs:
+  //   * wavefront 15: loader of the VALUE rows (frame and pattern samples) + the halo sums;
+  //   * with a spare wavefront (n_act <= 14), wavefront 14 is a second loader for the STATISTICS rows (mean / reciprocal
+  //     deviation planes, needed by output rows only): the halo sums need the values alone, so nobody waits for it
+  //     but the barrier, and the first loader's chunk drops from 24 DMA instructions to 8;
+  //   * with two spare wavefronts (n_act == 13) the last pair is SPLIT: wavefront 12 takes its first disparity,
+  //     wavefront 13 the second -- SIMDs 0 and 1 then carry 3.5 pairs each, 2 and 3 carry 3 pairs and a loader,
+  //     instead of 4 / 3 / 3 / 3 + loader.
+  const bool has_helper = n_act <= kAWaves - 1;
+  const bool split_last = n_act == kAWaves - 2;
+  const int n_out_rows = h_hi - h_lo;
+  auto chunk_is_light = [&](int ch) { return alld_chunk_is_light<ROWS>(ch, n_out_rows); };
+  constexpr int LV = ROWS * kAValuesPerRow, LS = ROWS * kAStatsPerRow;   // DMA instructions per chunk: values, statistics
+  static_assert(LV + LS < 64, "in-flight DMA count must fit vmcnt");
+  static_assert(kABufs == 3, "the loaders run two chunks ahead of the consumers");
+  const int c_lo = w_lo - 4;
+  const int total = n_pass * n_chunks;                             // chunks of the whole workgroup, all passes
+  const AlldStatsArgs sa = {m0 + (long)f * H * Wp + 4, v0 + (long)f * H * Wp + 4, m1 + (long)f * st1_frame_stride,
+                            v1 + (long)f * st1_frame_stride, lds, Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs};
+
+  if (wave == kAWaves - 1 && has_helper) {
+    // ------------------------------ statistics loader (spare consumer wavefront) ------------------------------
+    alld_stats_loader<ROWS>(sa, lane);
+#ifdef CTD_STAMPS
+    dump_stamps();
+#endif
+    return;                                                        // (the emit rows are dealt to the consumer wavefronts only)
+  }
   if (wave == kAWaves) {
     // every chunk barrier waits for this wavefront's DMA issue and halo sums: it goes first on its SIMD
     __builtin_amdgcn_s_setprio(3);
-    // ------------------------------ loader + halo wavefront ------------------------------
-    const float* a_img = ac + (long)f * H * Wp + 4;               // +4: column c lives at c + 4
-    const float* m0i = m0 + (long)f * H * Wp + 4;
-    const float* v0i = v0 + (long)f * H * Wp + 4;
+    // ------------------------------ value loader + halo wavefront ------------------------------
+    const float* a_img = ac + (long)f * H * Wp + 4;
     const float* b_img = bc + (long)f * st1_frame_stride;
-    const float* m1i = m1 + (long)f * st1_frame_stride;
-    const float* v1i = v1 + (long)f * st1_frame_stride;
-    const int c_lo = w_lo - 4;
     const int aq0 = min(c_lo + 4 * lane, Wp - 8), aq1 = min(c_lo + 256 + 4 * lane, Wp - 8);
     const bool a_tail = 256 + 4 * lane < kAA, s_tail = 256 + 4 * lane < kASpanPad;
-    const int total = n_pass * n_chunks;                           // chunks of the whole workgroup, all passes
     int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;                 // the next chunk to issue: ring slot, pass, chunk in the pass
-    auto issue_chunk = [&]() {
+    auto issue_chunk = [&]() {                                     // returns whether the statistics went with it
       float* buf = lds + i_slot * (ROWS * kAPack);
       const int i_grp = i_pass + rot >= n_pass ? i_pass + rot - n_pass : i_pass + rot;
       const int xb = c_lo - (i_grp * dgs + dgs - 1);               // unclamped pattern column of span slot 0
       const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
 #pragma unroll
-      for (int s = 0; s < ROWS; ++s) {
-        const int r = r_begin + i_ch * ROWS + s;
+      for (int s2 = 0; s2 < ROWS; ++s2) {
+        const int r = r_begin + i_ch * ROWS + s2;
         const int rc = clampi(r, 0, H - 1);
-        // statistics of output row r - TAIL; product rows that complete no output of the band re-read a row the band
-        // needs anyway (no cache lines of their own)
-        const int hs = clampi(r - TAIL, h_lo, h_hi - 1);
-        float* pk = buf + s * kAPack;
+        float* pk = buf + s2 * kAPack;
         dma_quad(a_img + (long)rc * Wp + aq0, pk);
-        dma_quad(m0i + (long)hs * Wp + aq0, pk + kAA);
-        dma_quad(v0i + (long)hs * Wp + aq0, pk + 2 * kAA);
         dma_quad(b_img + (long)rc * W1 + sq0, pk + kAOffB);
-        dma_quad(m1i + (long)hs * W1 + sq0, pk + kAOffB + kASpanPad);
-        dma_quad(v1i + (long)hs * W1 + sq0, pk + kAOffB + 2 * kASpanPad);
-        if (a_tail) {
-          dma_quad(a_img + (long)rc * Wp + aq1, pk + 256);
-          dma_quad(m0i + (long)hs * Wp + aq1, pk + kAA + 256);
-          dma_quad(v0i + (long)hs * Wp + aq1, pk + 2 * kAA + 256);
-        }
-        if (s_tail) {
-          dma_quad(b_img + (long)rc * W1 + sq1, pk + kAOffB + 256);
-          dma_quad(m1i + (long)hs * W1 + sq1, pk + kAOffB + kASpanPad + 256);
-          dma_quad(v1i + (long)hs * W1 + sq1, pk + kAOffB + 2 * kASpanPad + 256);
-        }
+        if (a_tail) dma_quad(a_img + (long)rc * Wp + aq1, pk + 256);
+        if (s_tail) dma_quad(b_img + (long)rc * W1 + sq1, pk + kAOffB + 256);
       }
+      const bool with_stats = !has_helper && !chunk_is_light(i_ch);
+      if (with_stats) alld_issue_stats<ROWS>(sa, i_pass, i_ch, i_slot, lane);
       ++i_n;
       i_slot = i_slot == kABufs - 1 ? 0 : i_slot + 1;
       if (++i_ch == n_chunks) { i_ch = 0; ++i_pass; }
+      return with_stats;
     };
-    // halo job of this lane: consumer wave cw, disparity j, side (0 = quad left of the tile, 1 = right of it)
+    // halo job of this lane: consumer pair cw, disparity j, side (0 = quad left of the tile, 1 = right of it)
     const int cw = lane >> 2, hj = (lane >> 1) & 1, side = lane & 1;
     const bool has_job = cw < n_act;
     const int a_slot = side ? (kAA - 4) : 0;
@@ -1849,15 +2027,15 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
       constexpr int UB = decltype(ub_tag)::value;
       const float* buf = lds + h_slot * (ROWS * kAPack);
 #pragma unroll
-      for (int s = 0; s < ROWS; ++s) {
-        const int u = (UB + s) % 6;
-        const float* pk = buf + s * kAPack;
+      for (int s2 = 0; s2 < ROWS; ++s2) {
+        const int u = (UB + s2) % 6;
+        const float* pk = buf + s2 * kAPack;
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = has_job ? pk[a_slot + i] * pk[kAOffB + b_slot + i] : 0.f;
-          const float t3 = p + hP[i][(u + 1) % 2] + hP[i][u % 2];
-          hP[i][u % 2] = p;
+          const float p2 = has_job ? pk[a_slot + i] * pk[kAOffB + b_slot + i] : 0.f;
+          const float t3 = p2 + hP[i][(u + 1) % 2] + hP[i][u % 2];
+          hP[i][u % 2] = p2;
           x[i] = t3 + hT[i][(u + 3) % 6] + hT[i][u % 6];
           hT[i][u % 6] = t3;
         }
@@ -1874,12 +2052,13 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
       }
       h_slot = h_slot == kABufs - 1 ? 0 : h_slot + 1;
     };
-    constexpr int L = ROWS * kADmaPerRow;
-    static_assert(L * (kABufs - 2) < 64, "in-flight DMA count must fit vmcnt");
-    static_assert(kABufs == 3, "the loader runs two chunks ahead of the consumers");
+    // after issuing chunk X (LV value DMAs, + LS statistics DMAs when it carried them) everything older has landed once
+    // at most that many are outstanding
+    auto wait_older = [&](bool with_stats) {
+      if (with_stats) wait_vmcnt<LV + LS>(); else wait_vmcnt<LV>();
+    };
     issue_chunk();                                                 // total >= 2 (a pass has CPI >= 2 chunks)
-    issue_chunk();
-    wait_vmcnt<L>();                                               // chunk 0 has landed
+    wait_older(issue_chunk());                                     // chunk 0 has landed
     halo_chunk(std::integral_constant<int, 0>{});
     wait_lgkmcnt0();
     wg_barrier();
@@ -1889,8 +2068,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
 #pragma unroll
       for (int cc = 0; cc < CPI; ++cc) {
         if (i_n < total) {
-          issue_chunk();
-          wait_vmcnt<L>();                                         // chunk g + cc + 1 has landed
+          wait_older(issue_chunk());                               // chunk g + cc + 1 has landed
         } else {
           wait_vmcnt<0>();
         }
@@ -1900,25 +2078,48 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
           else halo_chunk(std::integral_constant<int, (3 % CPI) * ROWS>{});
         }
         wait_lgkmcnt0();
+        CTD_STAMP_ARRIVE(st_lds, kAWaves, (g + cc) / n_chunks, (g + cc) % n_chunks, lane);
         wg_barrier();
+        CTD_STAMP_LEAVE(st_lds, kAWaves, (g + cc) / n_chunks, (g + cc) % n_chunks, lane);
       }
     }
+#ifdef CTD_STAMPS
+    dump_stamps();
+#endif
     return;
   }
 
-  // two copies of the consumer loop: the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * wave) % 4
-  if ((dgs - 2 - 2 * wave) & 2)
-    alld_consume<MODE, 2, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
-  else
-    alld_consume<MODE, 0, ROWS>(lds, rank_lds, out, wave, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D);
+  // Consumers.  Two copies of the regular loop -- the sub-quad shift of the pattern-side operands, (dgs - 2 - 2 * pair) % 4,
+  // alternates with the pair index -- and, for a split last pair, one copy per half.
+  {
+    const int pair = (split_last && wave == n_act) ? n_act - 1 : wave;
+    const bool ks2 = ((dgs - 2 - 2 * pair) & 2) != 0;
+    if (split_last && wave >= n_act - 1) {
+      if (wave == n_act - 1) {
+        if (ks2) alld_consume<MODE, 2, ROWS, 1>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+        else alld_consume<MODE, 0, ROWS, 1>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+      } else {
+        if (ks2) alld_consume<MODE, 2, ROWS, 2>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+        else alld_consume<MODE, 0, ROWS, 2>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+      }
+    } else if (ks2) {
+      alld_consume<MODE, 2, ROWS>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+    } else {
+      alld_consume<MODE, 0, ROWS>(lds, rank_lds, out, pair, f, lane, w_lo, h_lo, h_hi, r_begin, n_iters, n_pass, rot, dgs, H, W, D, wave);
+    }
+  }
 
+#ifdef CTD_STAMPS
+  if constexpr (!RANK) { dump_stamps(); return; }
+#endif
   if constexpr (!RANK) return;                                     // plain volume call: nothing to emit
   // ---- emit: the band's final {top, second} -> index, best score, work-list flag.  The last chunk barrier (behind
   // every wavefront's lgkmcnt(0)) has made all slot updates visible.
   const unsigned l4 = 4u * (unsigned)lane;
   const bool lane_out = w_lo + (int)l4 < W;
   const unsigned margin = rank_eps >= 0.f ? key_margin_units(rank_eps) : 0u;
-  for (int row = wave; row < h_hi - h_lo; row += kAWaves) {
+  const int n_emit = has_helper ? kAWaves - 1 : kAWaves;           // wavefronts that reach this point
+  for (int row = wave; row < h_hi - h_lo; row += n_emit) {
     const unsigned* sl = rank_lds + row * 512 + lane;
     const long p0 = ((long)f * H + h_lo + row) * W + w_lo + l4;    // first of the lane's four pixels
     long d64[4];
@@ -1962,6 +2163,9 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
         if (hard[i]) *dst++ = p0 + i;
     }
   }
+#ifdef CTD_STAMPS
+  dump_stamps();
+#endif
 }
 
 struct FastWorkspace {
@@ -2077,6 +2281,9 @@ static AlldPlan alld_plan(int frames, int H, int W, int D) {
   ap.bands = ceil_div(H, ap.band_rows);
   ap.band_rows = ceil_div(H, ap.bands);                          // the same number of bands, evenly tall
   ap.lds = (size_t)ap.band_rows * 2048 + sizeof(float) * kABufs * ap.chunk_rows * kAPack;
+#ifdef CTD_STAMPS
+  ap.lds += sizeof(unsigned) * kStampWords;
+#endif
   return ap;
 }
 
@@ -2141,7 +2348,10 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     // plain volume, single channel: the all-D kernel without the ranking (the same bits as with it)
     const AlldPlan ap = alld_plan(frames, H, W, D);
     const int n_items = ceil_div(W, 256) * ap.bands * frames;
-    const size_t lds = sizeof(float) * kABufs * ap.chunk_rows * kAPack;
+    size_t lds = sizeof(float) * kABufs * ap.chunk_rows * kAPack;
+#ifdef CTD_STAMPS
+    lds += sizeof(unsigned) * kStampWords;
+#endif
     dim3 grid(n_items), block(64 * (kAWaves + 1));
     auto kern = ap.chunk_rows == 3 ? ncc_fast_alld_kernel<kAStore, 3> : ncc_fast_alld_kernel<kAStore, 2>;
     CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2333,3 +2543,14 @@ int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_str
 }
 
 }  // namespace ctd
+
+#ifdef CTD_STAMPS
+extern "C" int ctd_debug_read_stamps(void* dst, size_t bytes) {
+  const size_t have = sizeof(unsigned) * ctd::kStampWgs * ctd::kStampWords;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ctd::g_stamps), bytes < have ? bytes : have);
+}
+extern "C" int ctd_debug_stamp_layout(int* words_per_wg, int* chunks, int* pass) {
+  *words_per_wg = ctd::kStampWords; *chunks = ctd::kStampChunks; *pass = CTD_STAMP_PASS;
+  return 0;
+}
+#endif
