@@ -50,7 +50,7 @@ void timing_end(hipStream_t stream, int columns) {
 
 extern "C" {
 
-int ctd_version(void) { return 3; }
+int ctd_version(void) { return 4; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;
@@ -346,17 +346,24 @@ int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_st
                      (hipStream_t)stream);
 }
 
+size_t ctd_costvol_workspace_bytes(int frames, int H, int W, int D, int block_size, int type, int per_frame_pattern) {
+  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3) return 0;
+  if (!costvol_sep_supported(H, W, D, block_size, type)) return 0;          // the other kernels need none
+  return costvol_sep_workspace_bytes(frames, H, W, D, per_frame_pattern != 0);
+}
+
 int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost, int frames, int H,
-                    int W, int D, int block_size, int type, float eps, int device, void* stream) {
-  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0 ||
-      false)
+                         int W, int D, int block_size, int type, float eps, void* workspace, size_t workspace_bytes,
+                         int device, void* stream) {
+  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || type < 0 || type > 3 || pattern_frame_stride < 0)
     return CTD_ERR_INVALID_ARG;
   if (frames == 0) return CTD_OK;
   if (!im || !pattern || !cost) return CTD_ERR_INVALID_ARG;
+  if (pattern_frame_stride != 0 && pattern_frame_stride != (long)H * W) return CTD_ERR_INVALID_ARG;
   DeviceGuard g(device);
   if (g.status) return g.status;
-  return costvol_fast_f32(im, pattern, pattern_frame_stride, cost, frames, H, W, D, block_size, type, eps,
-                     (hipStream_t)stream);
+  return costvol_fast_f32(im, pattern, pattern_frame_stride, cost, frames, H, W, D, block_size, type, eps, workspace,
+                          workspace_bytes, (hipStream_t)stream);
 }
 
 int ctd_disp_to_depth_fwd_f32(const float* disp, float* depth, long n, float baseline_focal, int device, void* stream) {

@@ -52,6 +52,12 @@ int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int fr
 int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,
                           int D, int bs, void* workspace, const RankPlan& rank, const float* best, hipStream_t stream);
 
+// separable block SAD / MSE cost volume through the all-D pipeline (block 9, W % 4 == 0); workspace = padded operand planes
+bool costvol_sep_supported(int H, int W, int D, int bs, int type);
+size_t costvol_sep_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern);
+int costvol_sep_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W, int D,
+                    int type, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 // argmax_rerank.hip
 int argmax_rerank_f32(const float* vol, const float* in0, const float* in1, long in1_frame_stride, int64_t* idx,
                       float* best, int frames, int D, int H, int W, int bs, float eps, void* workspace,
@@ -92,7 +98,7 @@ int pattern_loss_multi_bwd_f32(int n_levels, const ctd_pattern_level* levels, co
                                int type, float eps, hipStream_t stream);
 
 int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W,
-                     int D, int bs, int type, float eps, hipStream_t stream);
+                     int D, int bs, int type, float eps, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);

@@ -1507,6 +1507,10 @@ constexpr int kAOffB = 3 * kAA, kAOffH = 3 * kAA + 3 * kASpanPad;
 // band height limit: rank slots (2 KB per row) + staging ring <= 160 KB -- 44 rows with 3-row chunks, 57 with 2-row chunks
 constexpr int alld_max_band_rows(int rows) { return (160 * 1024 - (int)sizeof(float) * kABufs * rows * kAPack) / 2048; }
 constexpr int kAStore = 1, kARank = 2;          // MODE bits of the all-D kernel: materialise the volume / rank the scores
+// Block SAD / MSE cost volume through the same pipeline (with kAStore, never with kARank): the per-pixel
+// plane |P[r][c - d] - I[r][c]| (squared for MSE) takes the place of the product a * b, and its 9 x 9 window sum / 81 is the
+// output -- no statistics rows, no normalisation.  See costvol_sep_f32.
+constexpr int kASad = 4, kAMse = 8;
 constexpr int kAllowTwoRowChunks = 2;           // 3: never use 2-row chunks
 constexpr double kTwoRowPenalty = 1.03;
 constexpr int kTagBits = 9;                    // D <= 512
@@ -1602,7 +1606,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
   int slot = 0;                                                    // ring slot of the current chunk
   f32x4 qa, qb0, qb1;                                              // value quads of the row (frame, pattern x 2)
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int grp = pass + rot >= n_pass ? pass + rot - n_pass : pass + rot;
+    const int grp = pass + rot;                                    // (rot: the workgroup's first disparity group)
     const int d_base = grp * dgs + WAVE * 2;
     if (WAVE * 2 >= dgs || d_base + J0 >= D) {
       // a wavefront without disparities in this pass (the pass is narrower than 15 pairs, or it is the last pass and
@@ -1665,7 +1669,15 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             float sP = P[j][i][(u + 1) % 2] + P[j][i][u % 2];
             float sT = T[j][i][(u + 3) % 6] + T[j][i][u % 6];
             asm("" : "+v"(sP), "+v"(sT));                          // (formed before the slots are reused)
-            const float p = av[i] * be[kS + (1 - j) + i];          // b[j][i] = slot kOff0 - j + i
+            float p;                                               // b[j][i] = slot kOff0 - j + i
+            if constexpr ((MODE & kASad) != 0) {
+              p = fabsf(av[i] - be[kS + (1 - j) + i]);
+            } else if constexpr ((MODE & kAMse) != 0) {
+              const float df = av[i] - be[kS + (1 - j) + i];
+              p = df * df;
+            } else {
+              p = av[i] * be[kS + (1 - j) + i];
+            }
             const float t3 = p + sP;
             P[j][i][u % 2] = p;
             x[j][i] = t3 + sT;
@@ -1681,9 +1693,13 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
           }
         };
         if (row_out) {
-          f32x4 qma = quad(own + kAA), qsa = quad(own + 2 * kAA);
-          f32x4 qm0 = quad(pat + kASpanPad), qm1 = quad(pat + kASpanPad + 4);
-          f32x4 qs0 = quad(pat + 2 * kASpanPad), qs1 = quad(pat + 2 * kASpanPad + 4);
+          constexpr bool COST = (MODE & (kASad | kAMse)) != 0;      // SAD / MSE cost volume: no statistics, no normalisation
+          f32x4 qma, qsa, qm0, qm1, qs0, qs1;
+          if constexpr (!COST) {
+            qma = quad(own + kAA), qsa = quad(own + 2 * kAA);
+            qm0 = quad(pat + kASpanPad), qm1 = quad(pat + kASpanPad + 4);
+            qs0 = quad(pat + 2 * kASpanPad), qs1 = quad(pat + 2 * kASpanPad + 4);
+          }
           float me[8], se[8];
           unsigned key[2][4];
 #pragma unroll
@@ -1700,12 +1716,14 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
             suf[0] = suf[1] + x[j][0];
             float sj[4];
             window_combine4(suf, pre[3], pre, sj);                  // wave-edge lanes get 0 from the missing neighbour
-            if (j == J0) {
-              // statistics quads: pinned after the first window sums (data dependency keeps the wait here)
-              asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
-              asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
+            if constexpr (!COST) {
+              if (j == J0) {
+                // statistics quads: pinned after the first window sums (data dependency keeps the wait here)
+                asm("" : "+v"(qma), "+v"(qsa), "+v"(qm0), "+v"(qm1) : "v"(sj[0]), "v"(sj[3]));
+                asm("" : "+v"(qs0), "+v"(qs1) : "v"(sj[0]), "v"(sj[3]));
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
+                for (int k = 0; k < 4; ++k) { me[k] = qm0[k]; me[4 + k] = qm1[k]; se[k] = qs0[k]; se[4 + k] = qs1[k]; }
+              }
             }
             f32x4 hq = quad(hqp + j * 2 * 4);
             asm("" : "+v"(hq));
@@ -1714,10 +1732,14 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float sh = fmaf(halo_mask, hq[i], sj[i]);
-              const float cov = fmaf(qma[i], me[kS + (1 - j) + i], sh);   // qma = -bs^2 * (window mean), from the pre-pass
-              const float inv = ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
-              if (STORE) val[i] = cov * inv;                        // the same bits as the plain volume kernels'
-              if constexpr (RANK) key[j][i] = (__float_as_uint(fmaf(cov, inv, kKeyBias)) << kTagBits) | (tag0 - (unsigned)j);
+              if constexpr (COST) {
+                val[i] = sh * (1.f / 81.f);                         // mean over the 9 x 9 block
+              } else {
+                const float cov = fmaf(qma[i], me[kS + (1 - j) + i], sh);   // qma = -bs^2 * (window mean), from the pre-pass
+                const float inv = ncc_inv_norm(qsa[i], se[kS + (1 - j) + i]);
+                if (STORE) val[i] = cov * inv;                      // the same bits as the plain volume kernels'
+                if constexpr (RANK) key[j][i] = (__float_as_uint(fmaf(cov, inv, kKeyBias)) << kTagBits) | (tag0 - (unsigned)j);
+              }
             }
             if (STORE && lane_out && d < D) {
               long ooff = (long)d * HW + (long)h * W;
@@ -1806,7 +1828,7 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
 struct AlldStatsArgs {
   const float *m0i, *v0i, *m1i, *v1i;       // this frame's mean / reciprocal-deviation planes (frame side: column c at c + 4)
   float* lds;                               // staging ring
-  int Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs;
+  int Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs, first_grp;
 };
 constexpr int kAStatsPerRow = 8, kAValuesPerRow = 4;   // dwordx4 LDS-DMA instructions per staged row
 
@@ -1817,7 +1839,7 @@ __device__ __forceinline__ void alld_issue_stats(const AlldStatsArgs& a, int ip,
   const int aq0 = min(a.c_lo + 4 * lane, a.Wp - 8), aq1 = min(a.c_lo + 256 + 4 * lane, a.Wp - 8);
   const bool a_tail = 256 + 4 * lane < kAA, s_tail = 256 + 4 * lane < kASpanPad;
   float* buf = a.lds + sl * (ROWS * kAPack);
-  const int xb = a.c_lo - (ip * a.dgs + a.dgs - 1);               // unclamped pattern column of span slot 0
+  const int xb = a.c_lo - ((ip + a.first_grp) * a.dgs + a.dgs - 1);   // unclamped pattern column of span slot 0
   const int sq0 = min(xb + a.xoff + 4 * lane, a.W1 - 4), sq1 = min(xb + a.xoff + 256 + 4 * lane, a.W1 - 4);
 #pragma unroll
   for (int s2 = 0; s2 < ROWS; ++s2) {
@@ -1892,7 +1914,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const float* __restrict__ bc, const float* __restrict__ m1, const float* __restrict__ v1, long st1_frame_stride,
     float* __restrict__ out, int64_t* __restrict__ idx_out, float* __restrict__ best_out,
     unsigned char* __restrict__ flags_out, WorkList work, float rank_eps, int frames, int n_items, int H, int W, int D,
-    int band_rows, int n_pass, int dgs, int Wp, int W1, int xoff) {
+    int band_rows, int n_pass_all, int dgs, int Wp, int W1, int xoff, int n_psplit) {
   constexpr int HALF = 4, TAIL = 4, STEP = 6, CPI = STEP / ROWS;
   // [band_rows][top | second][256] rank slots first (their row base goes into one lane register), then the staging ring
   extern __shared__ float lds_all[];
@@ -1904,10 +1926,19 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   // contiguous range of the band-major list, so that co-resident workgroups share pattern rows in its L2 -- cut the
   // operand fetches from 2 x 99 to 2 x 59-68 MiB and were 1-2.5 % SLOWER in four A/B runs: the kernel is bound by vector
   // issue, not by its 5-10 % of operand traffic.  Pass order rotated per workgroup: slower as well.)
-  const int item = (int)blockIdx.x;
+  // Calls with few frames (one 1024 x 1024 frame is 4 column tiles) would need short bands to fill the chip, and every
+  // band pays 8 warm-up rows per pass: without a ranking the DISPARITY GROUPS of an item can go to `n_psplit` different
+  // workgroups instead (pass split fastest in the item number), each walking its share of the passes over a tall band.
+  int item = (int)blockIdx.x;
   if (item >= n_items) return;                                     // whole workgroup, before any barrier
+  const int ps = item % n_psplit;
+  item /= n_psplit;
+  const int ppg = (n_pass_all + n_psplit - 1) / n_psplit;          // passes per workgroup
+  const int rot = ps * ppg;                                        // first disparity group of this workgroup
+  const int n_pass = min(ppg, n_pass_all - rot);
+  if (n_pass <= 0) return;
   const int n_tiles = (W + 255) / 256;
-  const int n_bands = n_items / (frames * n_tiles);
+  const int n_bands = n_items / (frames * n_tiles * n_psplit);
   const int w_lo = (item % n_tiles) * 256;
   const int band = (item / n_tiles) % n_bands;
   const int f = item / (n_tiles * n_bands);
@@ -1918,7 +1949,6 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   const int n_iters = (n_rows + STEP - 1) / STEP;
   const int n_chunks = n_iters * CPI;                              // per pass; a multiple of CPI
   const int n_act = dgs / 2;                                       // consumer wavefronts with work
-  const int rot = 0;                                               // first disparity group of this workgroup (pass p works on group (p + rot) % n_pass)
 #ifdef CTD_STAMPS
   unsigned* const st_lds = (unsigned*)(lds + kABufs * ROWS * kAPack);
   for (int k = threadIdx.x; k < kStampWords; k += 64 * (kAWaves + 1)) st_lds[k] = 0u;
@@ -1957,7 +1987,8 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   //   * with two spare wavefronts (n_act == 13) the last pair is SPLIT: wavefront 12 takes its first disparity,
   //     wavefront 13 the second -- SIMDs 0 and 1 then carry 3.5 pairs each, 2 and 3 carry 3 pairs and a loader,
   //     instead of 4 / 3 / 3 / 3 + loader.
-  const bool has_helper = n_act <= kAWaves - 1;
+  constexpr bool COST = (MODE & (kASad | kAMse)) != 0;             // SAD / MSE cost volume: value rows only, no statistics
+  const bool has_helper = !COST && n_act <= kAWaves - 1;
   const bool split_last = n_act == kAWaves - 2;
   const int n_out_rows = h_hi - h_lo;
   auto chunk_is_light = [&](int ch) { return alld_chunk_is_light<ROWS>(ch, n_out_rows); };
@@ -1967,7 +1998,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
   const int c_lo = w_lo - 4;
   const int total = n_pass * n_chunks;                             // chunks of the whole workgroup, all passes
   const AlldStatsArgs sa = {m0 + (long)f * H * Wp + 4, v0 + (long)f * H * Wp + 4, m1 + (long)f * st1_frame_stride,
-                            v1 + (long)f * st1_frame_stride, lds, Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs};
+                            v1 + (long)f * st1_frame_stride, lds, Wp, W1, xoff, c_lo, r_begin, h_lo, h_hi, n_pass, n_chunks, dgs, rot};
 
   if (wave == kAWaves - 1 && has_helper) {
     // ------------------------------ statistics loader (spare consumer wavefront) ------------------------------
@@ -1988,7 +2019,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     int i_slot = 0, i_pass = 0, i_ch = 0, i_n = 0;                 // the next chunk to issue: ring slot, pass, chunk in the pass
     auto issue_chunk = [&]() {                                     // returns whether the statistics went with it
       float* buf = lds + i_slot * (ROWS * kAPack);
-      const int i_grp = i_pass + rot >= n_pass ? i_pass + rot - n_pass : i_pass + rot;
+      const int i_grp = i_pass + rot;
       const int xb = c_lo - (i_grp * dgs + dgs - 1);               // unclamped pattern column of span slot 0
       const int sq0 = min(xb + xoff + 4 * lane, W1 - 4), sq1 = min(xb + xoff + 256 + 4 * lane, W1 - 4);
 #pragma unroll
@@ -2001,7 +2032,7 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
         if (a_tail) dma_quad(a_img + (long)rc * Wp + aq1, pk + 256);
         if (s_tail) dma_quad(b_img + (long)rc * W1 + sq1, pk + kAOffB + 256);
       }
-      const bool with_stats = !has_helper && !chunk_is_light(i_ch);
+      const bool with_stats = !COST && !has_helper && !chunk_is_light(i_ch);
       if (with_stats) alld_issue_stats<ROWS>(sa, i_pass, i_ch, i_slot, lane);
       ++i_n;
       i_slot = i_slot == kABufs - 1 ? 0 : i_slot + 1;
@@ -2013,6 +2044,11 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
     const bool has_job = cw < n_act;
     const int a_slot = side ? (kAA - 4) : 0;
     const int b_slot = has_job ? a_slot + (dgs - 1) - (cw * 2 + hj) : 0;
+    // SAD / MSE: right of the image the per-pixel plane is a COPY of its last column (the tap column is clamped before
+    // the shift), not the pairing a[W-1], b[w0 - d] of the NCC border rule: the four halo columns right of the LAST tile
+    // all take the pattern sample of column W - 1 (span slot b_slot - 1).  (Images that end inside a tile: see
+    // cost_border_kernel.)
+    const bool copy_last = COST && side == 1 && w_lo + 256 == W;
     float hP[4][2], hT[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -2033,7 +2069,11 @@ __global__ __launch_bounds__(64 * (kAWaves + 1)) void ncc_fast_alld_kernel(
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p2 = has_job ? pk[a_slot + i] * pk[kAOffB + b_slot + i] : 0.f;
+          float p2 = 0.f;
+          if (has_job) {
+            const float av = pk[a_slot + i], bv = pk[kAOffB + (copy_last ? b_slot - 1 : b_slot + i)];
+            p2 = (MODE & kASad) ? fabsf(av - bv) : ((MODE & kAMse) ? (av - bv) * (av - bv) : av * bv);
+          }
           const float t3 = p2 + hP[i][(u + 1) % 2] + hP[i][u % 2];
           hP[i][u % 2] = p2;
           x[i] = t3 + hT[i][(u + 3) % 6] + hT[i][u % 6];
@@ -2251,11 +2291,14 @@ static RankPlan rank_plan(void* base, size_t offset, int frames, int H, int W, i
 // the band height.  One workgroup per CU is resident (LDS), every workgroup costs about (rows + 8 warm-up rows) x passes,
 // so the bands are chosen to minimise ceil(workgroups / 256) x (band rows rounded up to the 6-row unroll + 8).
 struct AlldPlan {
-  int n_pass, dgs, band_rows, bands, chunk_rows;
+  int n_pass, dgs, band_rows, bands, chunk_rows, n_psplit;
   size_t lds;
 };
-static AlldPlan alld_plan(int frames, int H, int W, int D) {
+// `ranked`: the workgroup keeps the ranking of its pixels in LDS (band height limited by the slots, every disparity in one
+// workgroup).  Otherwise the band may be as tall as the image and the passes may be split over workgroups.
+static AlldPlan alld_plan(int frames, int H, int W, int D, bool ranked = true) {
   AlldPlan ap;
+  ap.n_psplit = 1;
   // The disparities are dealt evenly over the ceil(D / 30) passes (D = 128: 5 x 26 on 13 wavefronts).  Four full passes
   // of 30 and a last one of 8 measured 4 % SLOWER: a pass costs about the same whether 13 or 15 wavefronts work in it
   // (the row's dependent chain and the chunk barrier, not the sum of the wavefronts' instructions), so the short pass
@@ -2276,6 +2319,20 @@ static AlldPlan alld_plan(int frames, int H, int W, int D) {
       const long wgs = base * ceil_div(H, rows);
       const double cost = (double)((wgs + 255) / 256) * (double)(ceil_div(rows + 8, 6) * 6) * (cr == 2 ? kTwoRowPenalty : 1.0);
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; ap.chunk_rows = cr; }
+    }
+  }
+  if (!ranked) {
+    // no rank slots: 3-row chunks, any band height; try every pass split
+    ap.chunk_rows = 3;
+    best_cost = -1;
+    for (int sp = 1; sp <= ap.n_pass; ++sp) {
+      const int ppg = ceil_div(ap.n_pass, sp);
+      if (ceil_div(ap.n_pass, ppg) != sp) continue;                // (the same passes per workgroup with fewer workgroups)
+      for (int rows = H; rows >= 4; --rows) {
+        const long wgs = base * ceil_div(H, rows) * sp;
+        const double cost = (double)((wgs + 255) / 256) * ppg * (double)(ceil_div(rows + 8, 6) * 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; ap.n_psplit = sp; }
+      }
     }
   }
   ap.bands = ceil_div(H, ap.band_rows);
@@ -2339,15 +2396,15 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     hipLaunchKernelGGL(kern, grid, block, ap.lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
                        rank->idx, rank->best, rank->flags, rank->work, rank->eps, frames, n_items, H, W, D, ap.band_rows,
                        ap.n_pass, ap.dgs,
-                       ws.Wp, ws.W1, ws.xoff);
+                       ws.Wp, ws.W1, ws.xoff, 1);
     timing_end(stream, W);
     CTD_LAUNCH_CHECK();
     return CTD_OK;
   }
   if (BS == 9 && W % 4 == 0 && ((uintptr_t)out) % 16 == 0 && C == 1) {
     // plain volume, single channel: the all-D kernel without the ranking (the same bits as with it)
-    const AlldPlan ap = alld_plan(frames, H, W, D);
-    const int n_items = ceil_div(W, 256) * ap.bands * frames;
+    const AlldPlan ap = alld_plan(frames, H, W, D, false);
+    const int n_items = ceil_div(W, 256) * ap.bands * frames * ap.n_psplit;
     size_t lds = sizeof(float) * kABufs * ap.chunk_rows * kAPack;
 #ifdef CTD_STAMPS
     lds += sizeof(unsigned) * kStampWords;
@@ -2358,7 +2415,7 @@ static int launch_fast(const float* in0, const float* in1, long in1_frame_stride
     timing_begin(stream);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, ws.ac, ws.m0, ws.v0, ws.bc, ws.m1, ws.v1, st1_stride, out,
                        (int64_t*)nullptr, (float*)nullptr, (unsigned char*)nullptr, WorkList{}, -1.f, frames, n_items, H, W, D,
-                       ap.band_rows, ap.n_pass, ap.dgs, ws.Wp, ws.W1, ws.xoff);
+                       ap.band_rows, ap.n_pass, ap.dgs, ws.Wp, ws.W1, ws.xoff, ap.n_psplit);
     timing_end(stream, W);
     CTD_LAUNCH_CHECK();
     return CTD_OK;
@@ -2540,6 +2597,137 @@ int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_str
   const bool per_frame = in1_frame_stride != 0;
   FastWorkspace ws = fast_workspace(workspace, frames, 1, H, W, D, per_frame);
   return launch_fixup(in0, in1, in1_frame_stride, out, frames, 1, H, W, D, bs, ws, per_frame, &rank, best, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// Separable block SAD / MSE cost volume (block 9):
+//     cost[f][d][h][x] = 1/81 * sum over the 9 x 9 taps of g(P[r][clamp(c - d)] - I[r][c]),  r = clamp(h + dy), c = clamp(x + dx)
+// (the tap column is clamped BEFORE the shift, ext.h:231-243 composed with P_d[h][x] = P[h][clamp(x - d)]), i.e. the
+// replicate-border 9 x 9 box filter of the per-pixel plane q_d[r][c] = g(P[r][clamp(c - d)] - I[r][c]), g = |.| or (.)^2.
+// The all-D kernel in its kASad / kAMse mode filters that plane exactly like the NCC products: 3+3+3 vertical sums in
+// registers, the horizontal 9-sum by DPP, one subtract instead of 81 per output.  Its operand planes are plain padded
+// copies: frames with 4 replicate columns either side, the pattern per UNCLAMPED column x = c - d with the replicate
+// border baked in (cost_planes_kernel).  One difference to the NCC border rule: right of the image the NCC product
+// column w0 > W-1 pairs a[W-1] with b[w0 - d], here it must be a COPY of column W-1 (clamp before the shift) -- so the
+// halo right of the last column tile takes the pattern sample of column W-1 (loader), and for an image that ends INSIDE a
+// tile (W % 256 != 0) the outputs of its last four columns are recomputed by cost_border_kernel (taps summed directly).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cost_planes_kernel(const float* __restrict__ im, const float* __restrict__ pat,
+                                                          long pat_frame_stride, float* __restrict__ ac,
+                                                          float* __restrict__ bc, int frames, int n_pat, int H, int W, int Wp,
+                                                          int W1, int xoff) {
+  const long na = (long)frames * H * Wp, nb = (long)n_pat * H * W1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < na) {
+      const int c = (int)(i % Wp) - 4;
+      const long fh = i / Wp;
+      ac[i] = im[fh * W + clampi(c, 0, W - 1)];
+    } else {
+      const long k = i - na;
+      const int x = (int)(k % W1) - xoff;
+      const long ph = k / W1;                                      // pattern image * H + row
+      const long pimg = ph / H, h = ph - pimg * H;
+      bc[k] = pat[pimg * pat_frame_stride + h * W + clampi(x, 0, W - 1)];
+    }
+  }
+}
+
+// outputs (f, d, h, x) for the last four image columns x = W-4 .. W-1: thread per (f, d, h), the taps of its 9 x 8
+// neighbourhood summed in the reference's composition (tap column clamped, then shifted and clamped again)
+template <int TYPE>
+__global__ __launch_bounds__(256) void cost_border_kernel(const float* __restrict__ im, const float* __restrict__ pat,
+                                                          long pat_frame_stride, float* __restrict__ cost, int frames, int H,
+                                                          int W, int D) {
+  const long n = (long)frames * D * H;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  // (d fastest: neighbouring lanes read neighbouring pattern samples and the same image sample)
+  const int d = (int)(t % D), h = (int)((t / D) % H), f = (int)(t / ((long)H * D));
+  const float* I = im + (long)f * H * W;
+  const float* P = pat + (long)f * pat_frame_stride;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int dy = -4; dy <= 4; ++dy) {
+    const int r = clampi(h + dy, 0, H - 1);
+    float q[12];                                                   // q_d at columns W-8 .. W+3 (the last four: copies of W-1)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int c = clampi(W - 8 + k, 0, W - 1);
+      const float df = P[(long)r * W + clampi(c - d, 0, W - 1)] - I[(long)r * W + c];
+      q[k] = TYPE == 0 ? df * df : fabsf(df);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {                                   // output column W-4+o: q index 4+o, window o .. o+8
+      float s9 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s9 += q[o + k];
+      acc[o] += s9;
+    }
+  }
+  float* out = cost + (((long)f * D + d) * H + h) * W + (W - 4);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    if (W - 4 + o >= 0) out[o] = acc[o] * (1.f / 81.f);
+}
+
+struct CostPlanes {
+  int Wp, W1, xoff;
+  size_t off_b, bytes;
+};
+static CostPlanes cost_planes(int frames, int H, int W, int D, bool per_frame_pattern) {
+  CostPlanes cp;
+  const int Dpad = (D + kFDG - 1) / kFDG * kFDG + 32;              // (as fast_workspace: a last pass stages columns past D)
+  cp.xoff = Dpad + 3;
+  cp.W1 = (int)align_up((size_t)(W + 4 + cp.xoff), 4);
+  cp.Wp = (int)align_up((size_t)(W + 8), 4);
+  cp.off_b = align_up((size_t)frames * H * cp.Wp * sizeof(float), 256);
+  cp.bytes = cp.off_b + align_up((size_t)(per_frame_pattern ? frames : 1) * H * cp.W1 * sizeof(float), 256);
+  return cp;
+}
+
+bool costvol_sep_supported(int H, int W, int D, int bs, int type) {
+  return bs == 9 && (type == 0 || type == 1) && W % 4 == 0 && W >= 8 && H >= 1 && D <= 512;
+}
+
+size_t costvol_sep_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern) {
+  return cost_planes(frames, H, W, D, per_frame_pattern).bytes;
+}
+
+int costvol_sep_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W, int D,
+                    int type, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const bool per_frame = pat_frame_stride != 0;
+  const CostPlanes cp = cost_planes(frames, H, W, D, per_frame);
+  if (!workspace || workspace_bytes < cp.bytes || ((uintptr_t)workspace & 15)) return CTD_ERR_WORKSPACE;
+  if (((uintptr_t)cost) % 16 != 0) return CTD_ERR_UNSUPPORTED;
+  float* ac = (float*)workspace;
+  float* bc = (float*)((char*)workspace + cp.off_b);
+  const int n_pat = per_frame ? frames : 1;
+  hipLaunchKernelGGL(cost_planes_kernel, dim3(1024), dim3(256), 0, stream, im, pat, pat_frame_stride, ac, bc, frames, n_pat, H, W,
+                     cp.Wp, cp.W1, cp.xoff);
+  CTD_LAUNCH_CHECK();
+  const AlldPlan ap = alld_plan(frames, H, W, D, false);
+  const int n_items = ceil_div(W, 256) * ap.bands * frames * ap.n_psplit;
+  size_t lds = sizeof(float) * kABufs * ap.chunk_rows * kAPack;
+#ifdef CTD_STAMPS
+  lds += sizeof(unsigned) * kStampWords;
+#endif
+  dim3 grid(n_items), block(64 * (kAWaves + 1));
+  auto kern = type == 1 ? (ap.chunk_rows == 3 ? ncc_fast_alld_kernel<kAStore | kASad, 3> : ncc_fast_alld_kernel<kAStore | kASad, 2>)
+                        : (ap.chunk_rows == 3 ? ncc_fast_alld_kernel<kAStore | kAMse, 3> : ncc_fast_alld_kernel<kAStore | kAMse, 2>);
+  CTD_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long st1_stride = per_frame ? (long)H * cp.W1 : 0;
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, (const float*)ac, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)bc, (const float*)nullptr, (const float*)nullptr, st1_stride, cost, (int64_t*)nullptr,
+                     (float*)nullptr, (unsigned char*)nullptr, WorkList{}, -1.f, frames, n_items, H, W, D, ap.band_rows, ap.n_pass,
+                     ap.dgs, cp.Wp, cp.W1, cp.xoff, ap.n_psplit);
+  CTD_LAUNCH_CHECK();
+  if (W % 256 == 0) return CTD_OK;                                // (the loader's halo rule covers the right border)
+  const long nb = (long)frames * D * H;
+  if (type == 0)
+    hipLaunchKernelGGL(cost_border_kernel<0>, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, stream, im, pat, pat_frame_stride, cost, frames, H, W, D);
+  else
+    hipLaunchKernelGGL(cost_border_kernel<1>, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, stream, im, pat, pat_frame_stride, cost, frames, H, W, D);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
 }
 
 }  // namespace ctd

@@ -930,7 +930,12 @@ static int costvol_fast_type(int type, const float* im, const float* pat, long p
 }
 
 int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, float* cost, int frames, int H, int W,
-                     int D, int bs, int type, float eps, hipStream_t stream) {
+                     int D, int bs, int type, float eps, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  // SAD / MSE, block 9: the sum is separable (a replicate-border box filter of |P[r][c - d] - I[r][c]|) -- the all-D
+  // pipeline of ncc_fast.hip, one subtract per output instead of 81; needs the caller's workspace for the padded planes
+  if (workspace && costvol_sep_supported(H, W, D, bs, type) && ((uintptr_t)cost) % 16 == 0 &&
+      workspace_bytes >= costvol_sep_workspace_bytes(frames, H, W, D, pat_frame_stride != 0))
+    return costvol_sep_f32(im, pat, pat_frame_stride, cost, frames, H, W, D, type, workspace, workspace_bytes, stream);
   if (type >= 2) {                                   // census types: the census-transform kernel
     switch (bs) {
       case 3: return costvol_census_type<3>(type, im, pat, pat_frame_stride, cost, frames, H, W, D, eps, stream);

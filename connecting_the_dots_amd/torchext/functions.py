@@ -633,9 +633,16 @@ def costvol(im, pattern, n_disps, block_size, type='sad', eps=0.1, algo=None):
     stride = 0 if pattern.dim() == 2 else H * W
     D = int(n_disps)
     out = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
-    fn = _lib.lib().ctd_costvol_fast_f32 if _photo_fast(a, block_size, algo) else _lib.lib().ctd_costvol_f32
-    st = fn(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
-                                    _PHOTO_TYPES[type], float(eps), dev.index, _stream(dev))
+    L = _lib.lib()
+    if _photo_fast(a, block_size, algo):
+        # SAD / MSE, block 9: the separable path stages padded operand planes in a workspace (0 bytes: other kernels)
+        nws = L.ctd_costvol_workspace_bytes(N, H, W, D, int(block_size), _PHOTO_TYPES[type], 1 if stride else 0)
+        ws = _workspace(nws, dev) if nws else None
+        st = L.ctd_costvol_fast_f32(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
+                                    _PHOTO_TYPES[type], float(eps), _ptr(ws), nws, dev.index, _stream(dev))
+    else:
+        st = L.ctd_costvol_f32(_ptr(a), _ptr(pattern), stride, _ptr(out), N, H, W, D, int(block_size),
+                               _PHOTO_TYPES[type], float(eps), dev.index, _stream(dev))
     _lib.check(st, "costvol")
     return out[0] if squeeze else out
 

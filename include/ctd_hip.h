@@ -38,7 +38,7 @@ enum ctd_status {
   CTD_ERR_HIP = 1000           /* 1000 + hipError_t of the failing runtime call           */
 };
 
-int ctd_version(void);                       /* ABI version, currently 3 (2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
+int ctd_version(void);                       /* ABI version, currently 4 (4: ctd_costvol_fast_f32 takes a workspace, ctd_costvol_workspace_bytes; 2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
 const char* ctd_status_string(int status);
 
 /* (Bench instrumentation -- per-kernel device timing of the volume kernel -- is declared in ctd_hip_bench.h: it is not
@@ -169,10 +169,15 @@ int ctd_photometric_bwd_f64(const double* es, const double* ta, const double* gr
 int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
                     int frames, int H, int W, int D, int block_size, int type, float eps,
                     int device, void* stream);
-/* tolerance-level variant (odd block sizes 3/5/7/9): |fast - exact| <= 1e-5 |exact| + 1e-6 */
+/* tolerance-level variant (odd block sizes 3/5/7/9): |fast - exact| <= 1e-5 |exact| + 1e-6.
+ * SAD / MSE with block 9 and W % 4 == 0 are evaluated as a replicate-border 9 x 9 box filter of the per-pixel plane
+ * |P[r][clamp(c - d)] - I[r][c]| (one subtract per output instead of 81) by the NCC volume kernel's pipeline; that path
+ * needs `workspace` (ctd_costvol_workspace_bytes(), 16-byte aligned; 0 bytes / NULL: the LDS-tiled 81-tap kernel runs
+ * instead).  The census types use the census-transform kernel and no workspace.  (Signature since ABI version 4.) */
+size_t ctd_costvol_workspace_bytes(int frames, int H, int W, int D, int block_size, int type, int per_frame_pattern);
 int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
                     int frames, int H, int W, int D, int block_size, int type, float eps,
-                    int device, void* stream);
+                    void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * Local contrast normalisation, fused.  Replaces the op chain of LCN.tforward,

@@ -129,3 +129,22 @@ def test_lds_tiled_cost_volume_at_full_size(te, oracle, data, kind):
         ref = oracle.costvol(sn[r0:r0 + 12], pn[r0:r0 + 12], 48, BS, ty, 0.5, nthreads=8)
         lo, hi = strip_rows(r0)
         assert_close(fast[:48, r0 + lo:r0 + hi].cpu().numpy(), ref[:, lo:hi], what="%s strip at row %d" % (kind, r0))
+
+
+@pytest.mark.parametrize("kind", ["sad", "census_sad", "mse"])
+def test_cost_volumes_on_the_bench_frame_at_full_size(te, oracle, data, kind):
+    """the frame `bench.py --workload config4` times -- an LCN'd uniform random frame against the LCN'd dot pattern, not a
+    shifted pattern: every one of the 268 M outputs of the fast cost volumes (separable SAD / MSE, census transform)
+    within the float tolerance of the reference-order kernel, and strips against the oracle's composition directly"""
+    x, p = data
+    fast = te.costvol(x[0], p[0], D, BS, kind, 0.5, algo="fast")
+    exact = te.costvol(x[0], p[0], D, BS, kind, 0.5, algo="exact")
+    bad = (fast - exact).abs() > exact.abs() * 1e-5 + 1e-6
+    assert int(bad.sum()) == 0, "%d outputs outside tolerance, max |a-b| %.3e" % (int(bad.sum()), float((fast - exact).abs().max()))
+    del exact, bad
+    xn, pn = x[0].cpu().numpy(), p[0].cpu().numpy()
+    ty = {"mse": 0, "sad": 1, "census_sad": 3}[kind]
+    for r0 in STRIPS[:2]:
+        ref = oracle.costvol(xn[r0:r0 + 12], pn[r0:r0 + 12], 48, BS, ty, 0.5, nthreads=8)
+        lo, hi = strip_rows(r0)
+        assert_close(fast[:48, r0 + lo:r0 + hi].cpu().numpy(), ref[:, lo:hi], what="%s strip at row %d" % (kind, r0))

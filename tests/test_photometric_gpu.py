@@ -215,3 +215,30 @@ def test_costvol_fast_vs_oracle(te, oracle, ty, shape):
     ims, pats = np.stack([im, pat]), np.stack([pat, im])
     gb = te.costvol(dev(ims), dev(pats), D, bs, ty, 0.5, algo="fast").cpu().numpy()
     assert_close(gb[0], ref, what="batched")
+
+
+@pytest.mark.parametrize("ty", ["sad", "mse"])
+@pytest.mark.parametrize("shape", [(24, 64, 40), (13, 256, 33), (30, 260, 128), (20, 512, 28), (9, 8, 5), (40, 300, 27),
+                                   (5, 1028, 61), (12, 516, 1), (17, 128, 130)])
+def test_costvol_separable_sad_mse_vs_oracle(te, oracle, ty, shape):
+    """A6, SAD / MSE with block 9 and W % 4 == 0: the separable path (replicate-border box filter of |P[r][c-d] - I[r][c]|
+    through the NCC volume kernel's pipeline + the recomputed last four columns).  Every output against the oracle's
+    composition of photometric_loss_forward over shifted patterns: partial and exact column tiles, a tile plus four
+    columns, bands shorter than the block, D = 1 / 27 / 28 (14 pairs) / 61 / 128 (split pair) / 130, both image borders."""
+    H, W, D = shape
+    rs = np.random.RandomState(sum(shape))
+    im = rs.randn(H, W).astype(np.float32)
+    pat = rs.randn(H, W).astype(np.float32)
+    ref = oracle.costvol(im, pat, D, 9, TYPES.index(ty), 0.5, nthreads=4)
+    got = te.costvol(dev(im), dev(pat), D, 9, ty, 0.5, algo="fast").cpu().numpy()
+    assert_close(got, ref, what="separable costvol %s %s" % (ty, (shape,)))
+    for cols in (slice(0, 8), slice(W - 8, W)):                   # the border columns on their own (both clamps)
+        assert_close(got[..., cols], ref[..., cols], what="border columns")
+    # batched frames with per-frame patterns, and a shared pattern
+    ims, pats = np.stack([im, pat, im]), np.stack([pat, im, pat])
+    gb = te.costvol(dev(ims), dev(pats), D, 9, ty, 0.5, algo="fast").cpu().numpy()
+    assert_close(gb[0], ref, what="batched, per-frame patterns")
+    assert_close(gb[2], ref, what="batched, per-frame patterns (frame 2)")
+    gs = te.costvol(dev(ims), dev(pat), D, 9, ty, 0.5, algo="fast").cpu().numpy()
+    assert_close(gs[0], ref, what="batched, shared pattern")
+    assert np.array_equal(gs[0], gs[2])

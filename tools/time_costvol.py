@@ -12,7 +12,7 @@ for (H, W, D, N) in ((432, 512, 128, 4), (1024, 1024, 256, 1)):
     x, _ = te.lcn(fr.contiguous(), 5, 0.05)
     p, _ = te.lcn(pat.reshape(1, 1, H, W).contiguous(), 5, 0.05)
     x, p = x[:, 0].contiguous(), p[0, 0].contiguous()
-    for kind in ("sad", "census_sad", "census_mse"):
+    for kind in ("sad", "mse", "census_sad", "census_mse"):
         for _ in range(30):
             v = te.costvol(x, p, D, 9, kind, 0.5, algo="fast")
         torch.cuda.synchronize()
