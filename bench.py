@@ -169,13 +169,13 @@ def cpu_baseline(pattern_lcn_cpu, frames_lcn_cpu):
     return out
 
 
-def measured_traffic(kernel_substr):
+def measured_traffic(kernel_substr, pattern="*_pmc_hbm_traffic.json", exclude="config4"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc
     passes of tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
     WRITE_SIZE as is, both in KiB) and the file it was read from.  (None, None) when no profile of this build has
     been committed: the counters are NOT collected in this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern)) if not exclude or exclude not in os.path.basename(f))
     for f in reversed(files):
         for name, c in json.load(open(f)).items():
             if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -339,13 +339,29 @@ def run_config4(args):
         "roofline": {"bound": "hbm", "kernel": "ncc_fast_alld_kernel (volume + ranking over every disparity in one workgroup)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "avg_launch_ms": avg_ms.value,
-                     "launches": n_launch, "algorithmic_bytes_per_launch": kernel_units * bpp, "traffic": None,
-                     "traffic_source": None},
+                     "launches": n_launch, "algorithmic_bytes_per_launch": kernel_units * bpp},
         "census": {"kernel": "costvol_census_kernel<3, 9> (census transform staged per tap, v_sad_u32 accumulation)",
                    "avg_launch_ms": cen_ms, "value": units / (cen_ms * 1e-3) / 1e6, "unit": "Mpix*disp/s",
                    "bound": "valu (81 v_sad_u32 per output) -- priced against the volume's bytes anyway",
                    "achieved_GBs": cen_bytes / (cen_ms * 1e-3) / 1e9, "frac_of_hbm_peak": cen_bytes / (cen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    traffic, traffic_src = (measured_traffic("alld", "*_config4_pmc_hbm_traffic.json", None) if frames_n == 1 else (None, None))
+    out["roofline"]["traffic"] = traffic
+    out["roofline"]["traffic_source"] = (traffic_src + " (rocprofv3 --pmc passes of `bench.py --workload config4`, committed; not "
+                                         "collected in this run)") if traffic_src else None
+    # the separable SAD volume of the same frame (another GiB), device time
+    for _ in range(10):
+        te.costvol(x[:, 0], pat_lcn[0], D4, BS, "sad", 0.5, algo="fast")
+    e0.record()
+    for _ in range(args.steps):
+        sad = te.costvol(x[:, 0], pat_lcn[0], D4, BS, "sad", 0.5, algo="fast")
+    e1.record()
+    torch.cuda.synchronize()
+    sad_ms = e0.elapsed_time(e1) / args.steps
+    del sad
+    out["sad"] = {"kernel": "ncc_fast_alld_kernel in its SAD mode (box filter of |P[r][c-d] - I[r][c]|, one subtract per output) + "
+                            "operand-plane copy", "avg_call_ms": sad_ms, "value": units / (sad_ms * 1e-3) / 1e6, "unit": "Mpix*disp/s",
+                  "achieved_GBs": cen_bytes / (sad_ms * 1e-3) / 1e9, "frac_of_hbm_peak": cen_bytes / (sad_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # indices of the timed step's frame 0 against the reference-order kernel on the same LCN'd frame (first index on ties)
     ref_vol = te.xcorrvol_batch(x[:1].contiguous(), pat_lcn, D4, BS, algo="exact")
     ref_idx, _ = te.argmax_disp(ref_vol)
@@ -620,7 +636,7 @@ def main():
         # same LDS-limited residency, non-temporal) reaches on THIS card, measured now by the microbenchmark
         # tools/bin/ctd_store_ceiling (tools/ubench_src/store_ceiling.hip, built by __graft_entry__.build()); cards differ by
         # more than 10 % here (profiles/round3_store_ceiling.txt), so a committed number would not do
-        ceil_tbs, ceil_src, ceil_burst = None, None, None
+        ceil_tbs, ceil_src, ceil_burst, card_tbs, card_pat = None, None, None, None, None
         exe = os.path.join(ROOT, "tools", "bin", "ctd_store_ceiling")
         if workload == "config2" and world == 1 and os.path.exists(exe) and not args.headline_only:
             try:
@@ -635,16 +651,28 @@ def main():
                                     "(tools/bin/ctd_store_ceiling pattern %d)" % int(off[0]))
                     if line.startswith("all_d_pattern_store_only_burst_TBs"):
                         ceil_burst = float(line.split("=")[1])
+                    if line.startswith("card_best_store_only_TBs"):
+                        card_tbs = float(line.split("=")[1])
+                    if line.startswith("card_best_pattern"):
+                        card_pat = line.split("=", 1)[1].strip()
             except Exception:                                  # noqa: BLE001
                 pass
         if ceil_tbs is None:
             ceil_tbs = committed_number("round3_store_ceiling_summary.txt", "all_d_pattern_store_only_TBs")
             ceil_src = "profiles/round3_store_ceiling_summary.txt (another card: indicative only)" if ceil_tbs else None
         if ceil_tbs and achieved:
+            # two store-only rates measured on THIS card at the same 1.81 GB: the kernel's own pattern (26 planes per
+            # workgroup, 13 storing wavefronts per CU) and the best pattern known for the card (few wavefronts per CU writing
+            # interleaved contiguous pieces in step) -- the layout [N, D, H, W] does not let a workgroup that owns every
+            # disparity of its pixels write that way (profiles/round4_store_streams.txt)
             out["roofline"]["store_only_ceiling"] = {"GBs": ceil_tbs * 1e3, "frac_of_peak": ceil_tbs * 1e3 / HBM_PEAK_GBS,
                                                      "kernel_frac_of_it": achieved / (ceil_tbs * 1e3), "source": ceil_src}
             if ceil_burst:        # the same launches right after start-up: the card is not yet power-limited
                 out["roofline"]["store_only_ceiling"]["burst_GBs"] = ceil_burst * 1e3
+            if card_tbs:
+                out["roofline"]["store_only_ceiling"].update({
+                    "card_best_GBs": card_tbs * 1e3, "card_best_frac_of_peak": card_tbs * 1e3 / HBM_PEAK_GBS,
+                    "card_best_pattern": card_pat, "kernel_frac_of_card_best": achieved / (card_tbs * 1e3)})
         if geo is not None and n_exchanged[0]:
             last = ring[(n_exchanged[0] - 1) % len(ring)]
             if last[1] is not None:

@@ -1751,6 +1751,10 @@ __device__ __forceinline__ void alld_consume(float* lds, unsigned* rank_lds, flo
               // TIMING EXPERIMENT ONLY: chip-linear -- everything the 256 workgroups write in one row step is one window
               ooff = ((((((long)pass * (h_hi - h_lo) + (h - h_lo)) * gridDim.x + blockIdx.x) * dgs + (d - grp * dgs)) %
                        ((long)gridDim.x * (h_hi - h_lo) * D)) << 8) - ((long)f * D * HW + w_lo);
+#elif defined(CTD_STORE_AB) && CTD_STORE_AB == 4
+              // TIMING EXPERIMENT ONLY: every store lands in one 4 MB window (stays in L2 / the Infinity Cache): the
+              // instruction stream and the CU's store path as in the real kernel, no HBM write behind it
+              ooff = (ooff + (long)f * D * HW + w_lo) % (1L << 20) - ((long)f * D * HW + w_lo);
 #endif
               asm("" : "+s"(ooff));
               // written once, next read by another kernel after 1.8 GB more: non-temporal

@@ -90,6 +90,16 @@ __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ i
     __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// 512 streams (256 workgroups x 2 wavefronts), groups of k streams interleave their 1-KB segments into one contiguous
+// region (store_streams.hip's model with T = 2, S = 1): stream sg, segment r -> KB (sg / k) * k * R + r * k + sg % k
+template <int POLICY>
+__global__ __launch_bounds__(128) void interleaved_kernel(float* out, long R, long k) {
+  const long sg = (long)blockIdx.x * 2 + (threadIdx.x >> 6);
+  float* base = out + ((sg / k) * k * R + (sg % k)) * 256 + (threadIdx.x & 63) * 4;
+  const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+  for (long r = 0; r < R; ++r) store16<POLICY>(base + r * k * 256, v);
+}
+
 // the volume kernel's pattern: grid (column tiles of 256, bands, frames * disparity groups); all_d: one workgroup walks
 // every disparity group of its (tile, band, frame) in turn (the round-3 kernel), grid.z = frames
 template <int POLICY>
@@ -192,6 +202,33 @@ int main(int argc, char** argv) {
     best_us = 0.5f * (region() + region());
     printf("all_d_pattern_bands = %d\nall_d_pattern_store_only_burst_TBs = %.3f\n", bands, n * 4.0 / burst_us / 1e6);
     printf("all_d_pattern_store_only_us = %.1f\nall_d_pattern_store_only_TBs = %.3f\n", best_us, n * 4.0 / best_us / 1e6);
+    // The CARD's best store-only rate at the same 1.81 GB, sustained state (round 4, tools/ubench_src/store_streams.hip:
+    // profiles/round4_store_streams.txt): few wavefronts per CU writing interleaved contiguous pieces in step -- (i) the
+    // 256-workgroup x 256-thread grid-stride fill, (ii) 2 wavefronts per CU, groups of 64 streams interleaving 1-KB pieces.
+    // No kernel that owns 26 disparity planes per workgroup can write that way; reported as the second denominator.
+    auto timed = [&](auto launch) {
+      for (int i = 0; i < 40; ++i) launch();
+      hipEventRecord(ev_a);
+      for (int i = 0; i < 20; ++i) launch();
+      hipEventRecord(ev_b);
+      hipEventSynchronize(ev_b);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev_a, ev_b);
+      return ms * 50.f;
+    };
+    const float fill_us = timed([&] { hipLaunchKernelGGL(linear1k_kernel<0>, dim3(256), dim3(256), 0, 0, o, n / 4); });
+    const float fill_nt_us = timed([&] { hipLaunchKernelGGL(linear1k_kernel<1>, dim3(256), dim3(256), 0, 0, o, n / 4); });
+    const float il_us = timed([&] { hipLaunchKernelGGL(interleaved_kernel<0>, dim3(256), dim3(128), 0, 0, o, n / 256 / 512, 64); });
+    const float il_nt_us = timed([&] { hipLaunchKernelGGL(interleaved_kernel<1>, dim3(256), dim3(128), 0, 0, o, n / 256 / 512, 64); });
+    float card_us = fill_us;
+    const char* which = "256 x 256-thread grid-stride fill, plain";
+    if (fill_nt_us < card_us) { card_us = fill_nt_us; which = "256 x 256-thread grid-stride fill, nt"; }
+    if (il_us < card_us) { card_us = il_us; which = "2 wavefronts per CU, 64 streams interleaved, plain"; }
+    if (il_nt_us < card_us) { card_us = il_nt_us; which = "2 wavefronts per CU, 64 streams interleaved, nt"; }
+    printf("card_best_store_only_us = %.1f\ncard_best_store_only_TBs = %.3f\ncard_best_pattern = %s\n", card_us,
+           n * 4.0 / card_us / 1e6, which);
+    printf("card_fill_256wg_TBs = %.3f\ncard_fill_256wg_nt_TBs = %.3f\ncard_interleaved_2waves_TBs = %.3f\ncard_interleaved_2waves_nt_TBs = %.3f\n",
+           n * 4.0 / fill_us / 1e6, n * 4.0 / fill_nt_us / 1e6, n * 4.0 / il_us / 1e6, n * 4.0 / il_nt_us / 1e6);
     return 0;
   }
   const long n_vol = (long)F * D * H * W;            // 1.81 GB: config 2's volume
