@@ -52,7 +52,9 @@ const char* ctd_status_string(int status);
 
 /* algorithm selector of the NCC volume */
 #define CTD_NCC_EXACT 0   /* reference operation order, bit-identical to ext_cpu.cpp        */
-#define CTD_NCC_FAST 1    /* separable window sums; |a-b| <= 1e-5|b| + 1e-6 of the exact   */
+#define CTD_NCC_FAST 1    /* separable window sums; |a-b| <= 1e-5|b| + 1e-6 of the exact (C > 1: the sum of the
+                             channels' bounds -- the volume is the sum of per-channel NCCs, and where two channels
+                             cancel no f32 order keeps 1e-5 of the sum)                                     */
 
 /* --------------------------------------------------------------------------------------
  * Zero-mean NCC block-matching volume.

@@ -20,7 +20,17 @@ for case in range(cases):
     A = torch.from_numpy(a).cuda(); B = torch.from_numpy(b).cuda()
     ve = te.xcorrvol_batch(A, B, D, bs, algo="exact")
     vf = te.xcorrvol_batch(A, B, D, bs, algo="fast")
-    err = (vf - ve).abs() - (ve.abs() * 1e-5 + 1e-6)
+    # bound: the contract's 1e-5 |b| + 1e-6 PER CHANNEL -- the volume of C channels is the sum of C per-channel NCCs, each
+    # within its own bound; where two channels cancel (|sum| << |b_c|) no f32 evaluation order keeps 1e-5 of the SUM
+    # (seed 43, case 153: -0.57922 + 0.57827, each channel 2e-6 relative, the sum 1.7e-6 absolute)
+    if C == 1:
+        tol = ve.abs() * 1e-5 + 1e-6
+    else:
+        tol = torch.zeros_like(ve)
+        for c in range(C):
+            bc = (B[:, c:c + 1] if per_frame else B[c:c + 1]).contiguous()
+            tol += te.xcorrvol_batch(A[:, c:c + 1].contiguous(), bc, D, bs, algo="exact").abs() * 1e-5 + 1e-6
+    err = (vf - ve).abs() - tol
     ok = bool((err <= 0).all()) and bool(torch.isfinite(vf).all())
     if ok and C == 1 and not per_frame and bs == 9:
         h = te.prepare_pattern(B, N, D, bs)
