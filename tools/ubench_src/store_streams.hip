@@ -66,6 +66,23 @@ __global__ __launch_bounds__(1024) void streams_kernel(float* out, Cfg c) {
   }
 }
 
+// scattered streams with BURSTS: a wavefront visits its S streams in turn and writes `seg` contiguous KB per visit (seg
+// store instructions back to back) -- what store-only wavefronts fed from an LDS staging buffer would do (round 5 idea:
+// two such wavefronts per CU, 26 planes, both column tiles and 2-4 rows per visit)
+template <int NT>
+__global__ __launch_bounds__(1024) void burst_streams_kernel(float* out, int T, int S, long R, int seg) {
+  extern __shared__ float lds_unused[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= T) return;
+  const f32x4 v = {1.f, 2.f, 3.f, (float)wave};
+  const long sg0 = ((long)blockIdx.x * T + wave) * S;
+  for (long r = 0; r < R; r += seg)
+    for (int s = 0; s < S; ++s) {
+      float* p = out + ((sg0 + s) * R + r) * 256 + lane * 4;
+      for (int q = 0; q < seg; ++q) store16<NT>(p + q * 256, v);
+    }
+}
+
 // the all-D kernel's pattern: item = (tile, band, frame), tile fastest; pass g of n_dg; wave w writes planes g*2T + 2w + j
 template <int NT>
 __global__ __launch_bounds__(1024) void alld_kernel(float* out, int H, int W, int D, int band_rows, int n_dg, int T, int skew,
@@ -160,6 +177,23 @@ int main(int argc, char** argv) {
     row(Cfg{256, 13, 2, 0, 1, 0, pace});
     row(Cfg{256, 13, 2, 0, 1L << 40, 0, pace});
   }
+  // 3b. bursts: T store wavefronts per CU, 26 (or 52) streams per CU, seg KB contiguous per visit
+  CK(hipFuncSetAttribute((const void*)burst_streams_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)burst_streams_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  printf("# bursts: G workgroups x T store wavefronts x S streams, seg KB contiguous per visit\n");
+  printf("# %-4s %-3s %-3s %-4s | %9s %6s | %9s %6s\n", "G", "T", "S", "seg", "plain us", "TB/s", "nt us", "TB/s");
+  for (int G : {256, 128})
+    for (int T : {1, 2, 4})
+      for (int seg : {1, 2, 4, 8, 16}) {
+        const int S = (G == 256 ? 26 : 52) / T;
+        const long n_streams = (long)G * T * S;
+        long R = total_kb / n_streams / seg * seg;
+        const double bytes = (double)n_streams * R * 1024.0;
+        const double a = time_us([&] { hipLaunchKernelGGL(burst_streams_kernel<0>, dim3(G), dim3(64 * T), lds, 0, out, T, S, R, seg); }, warm, reps);
+        const double b = time_us([&] { hipLaunchKernelGGL(burst_streams_kernel<1>, dim3(G), dim3(64 * T), lds, 0, out, T, S, R, seg); }, warm, reps);
+        printf("  %-4d %-3d %-3d %-4d | %9.1f %6.2f | %9.1f %6.2f\n", G, T, S, seg, a, bytes / a / 1e6, b, bytes / b / 1e6);
+        fflush(stdout);
+      }
   // 4. the all-D kernel's own addressing and what its wavefronts could write at the same time instead
   printf("# all-D pattern: 13 waves x 2 planes, 5 passes, 54-row bands; skew / both tiles / pace / workgroup order\n");
   printf("# %-5s %-5s %-5s %-6s | %9s %6s | %9s %6s\n", "skew", "both", "pace", "order", "plain us", "TB/s", "nt us", "TB/s");
