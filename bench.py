@@ -40,6 +40,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step (BASELINE config 2 / 3: 16)")
     ap.add_argument("--algo", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--lcn-algo", default="fast", choices=["fast", "exact"],
+                    help="LCN of the frames inside the step: 'fast' = f32 sliding box sums (within 1e-5 |b| + 1e-6 of the "
+                         "reference, whose conv2d summation order is unspecified), 'exact' = f64 box sums (bit-identical to "
+                         "the oracle)")
     ap.add_argument("--workload", default=None, choices=["config2", "config3", "config4"],
                     help="default: config2 at one GPU, config3 (adds the geometric loss and its all-gather) at more; "
                          "config4 = BASELINE configs[3]: 1024x1024 frames, 256 disparities, NCC volume + argmax and the "
@@ -225,7 +229,7 @@ def also_measured(te, L, frames, pat_lcn, args):
     after the headline region, 20 repetitions each after 80 untimed ones, same inputs."""
     import ctypes
     import torch
-    x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+    x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS, algo=args.lcn_algo)
     L.ctd_kernel_timing_enable(1)
     for _ in range(80):                            # ~30 ms of the same work first: clocks (see the settle loop in main)
         te.xcorrvol_batch(x, pat_lcn, D, BS, algo="fast")
@@ -242,12 +246,12 @@ def also_measured(te, L, frames, pat_lcn, args):
              "achieved_GBs": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 if n else None,
              "frac_of_hbm_peak": units * BYTES_PER_PIXDISP / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
     for _ in range(80):
-        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS, algo=args.lcn_algo)
         te.xcorrvol_argmax(xx, pat_lcn, D, BS)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(20):
-        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        xx, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS, algo=args.lcn_algo)
         idx, _ = te.xcorrvol_argmax(xx, pat_lcn, D, BS)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
@@ -281,7 +285,7 @@ def run_config4(args):
     prepared = te.prepare_pattern(pat_lcn, frames_n, D4, BS)     # the pattern half of the matcher's pre-pass, once per run
 
     def step():
-        x, _ = te.lcn(fr, LCN_RADIUS, LCN_EPS)
+        x, _ = te.lcn(fr, LCN_RADIUS, LCN_EPS, algo=args.lcn_algo)
         idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D4, BS, return_volume=True, prepared=prepared)
         cen = te.costvol(x[:, 0], pat_lcn[0], D4, BS, "census_sad", 0.5, algo="fast")
         return x, idx, vol, cen
@@ -478,7 +482,7 @@ def main():
     n_exchanged = [0]
 
     def step(exchange=True):
-        x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS)
+        x, _ = te.lcn(frames, LCN_RADIUS, LCN_EPS, algo=args.lcn_algo)
         idx, best, vol = te.xcorrvol_argmax(x, pat_lcn, D, BS, return_volume=True, prepared=prepared)
         if geo is not None:
             # disparity -> depth (+1: disparity 0 would be depth 1e12) and the symmetric geometric loss of the frame
@@ -590,7 +594,7 @@ def main():
         achieved = kernel_units * BYTES_PER_PIXDISP / (avg_ms.value * 1e-3) / 1e9 if n_launch else None
         kernel = "ncc_fast_alld_kernel" if args.algo == "fast" else "ncc_exact_kernel"
         what = ("BASELINE config 2: batch=16 512x432 frames per GPU, 128 disparities, block 9, LCN(r=5,eps=0.05) + NCC "
-                "cost volume (materialised) + argmax; pattern LCN'd and prepared once per run") if workload == "config2" else (
+                "cost volume (materialised) + argmax; pattern LCN'd and prepared once per run; frame LCN algo=%s" % args.lcn_algo) if workload == "config2" else (
                 "BASELINE config 3: 16 frames per GPU (%d in all), LCN + NCC cost volume (materialised) + argmax + "
                 "disparity->depth + two-view geometric loss on frame pairs + all-gather of the loss scalar" % (world * args.frames))
         out = {

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ctd_costvol_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_costvol_fast_f32": (_c_int, [_vp, _vp, _c_long, _vp] + [_c_int] * 6 + [_c_float, _vp, _c_size_t, _c_int, _vp]),
     "ctd_lcn_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
+    "ctd_lcn_fast_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
     "ctd_lcn_datagen_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 4 + [_c_float, _c_int, _vp]),
     "ctd_disp_to_depth_fwd_f32": (_c_int, [_vp, _vp, _c_long, _c_float, _c_int, _vp]),
     "ctd_idx_to_depth_f32": (_c_int, [_vp, _vp, _c_long, _c_float, _c_float, _c_int, _vp]),

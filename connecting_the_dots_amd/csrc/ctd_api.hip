@@ -246,6 +246,17 @@ int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, i
   return lcn_f32(x, y, std_out, N, H, W, radius, eps, (hipStream_t)stream);
 }
 
+int ctd_lcn_fast_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius, float eps, int device,
+                     void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || radius < 0 || radius >= H || radius >= W || (double)H * W >= 2147483648.0)
+    return CTD_ERR_INVALID_ARG;
+  if (N == 0) return CTD_OK;
+  if (!x || !y || !std_out) return CTD_ERR_INVALID_ARG;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  return lcn_fast_f32(x, y, std_out, N, H, W, radius, eps, (hipStream_t)stream);
+}
+
 int ctd_lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W, int kernel_size, float eps,
                         int device, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || kernel_size < 0 || N > 65535) return CTD_ERR_INVALID_ARG;

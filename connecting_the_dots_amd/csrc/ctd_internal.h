@@ -102,6 +102,7 @@ int costvol_fast_f32(const float* im, const float* pat, long pat_frame_stride, f
 
 // lcn.hip
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
+int lcn_fast_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream);
 
 int lcn_datagen_f32(const float* img, float* out, float* out_std, int N, int H, int W, int ks, float eps,
                     hipStream_t stream);

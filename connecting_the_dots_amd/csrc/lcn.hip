@@ -152,6 +152,113 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tolerance-level variant (`algo = 'fast'`, radius 5): the same tile, the box sums in F32 as sliding windows -- the first
+// output of a run is a fresh 11-term sum, each next one adds the entering and subtracts the leaving tap (3 additions per
+// output and pass instead of 11 half-rate f64 ones), runs of 8 columns / 4 rows.  The contract for the LCN is a tolerance
+// (ATen's conv2d summation order is unspecified): every output within 1e-5 |b| + 1e-6 of the reference's
+// networks.LCN goldens and of the f64 kernel (tests/test_lcn_gpu.py); a sliding sum of at most 18 taps carries <= 14
+// roundings of the largest partial sum, 1e-7 relative on these positive sums.  Half the LDS (seven workgroups per CU).
+// ---------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    float* __restrict__ stds, int H, int W, float eps) {
+  constexpr int TRr = kLcnTH + 2 * R, TCc = kLcnTW + 2 * R, NTAP = 2 * R + 1;
+  __shared__ float rs1[TRr][kLcnTW], rs2[TRr][kLcnTW];            // row sums of x and x^2
+  __shared__ float tile[TRr][TCc];                                 // reflect-padded input
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * kLcnTW + tx;
+  const int w_lo = blockIdx.x * kLcnTW, h_lo = blockIdx.y * kLcnTH;
+  const long base = (long)blockIdx.z * H * W;
+  const float* xb = x + base;
+  for (int i0 = tid; i0 < TRr * TCc; i0 += kLcnTW * kLcnRows * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + kLcnTW * kLcnRows * u, TRr * TCc - 1);
+      const int r = i / TCc, c = i - r * TCc;
+      const int hh = reflect_idx(min(h_lo + r - R, H - 1 + R), H);
+      const int ww = reflect_idx(min(w_lo + c - R, W - 1 + R), W);
+      t[u] = xb[(long)hh * W + ww];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + kLcnTW * kLcnRows * u < TRr * TCc) (&tile[0][0])[i0 + kLcnTW * kLcnRows * u] = t[u];
+  }
+  __syncthreads();
+  // Everything below works on x - c, c = the tile's centre sample: (x - avg) / std and std do not change under a shift,
+  // and E[x^2] - avg^2 of the shifted samples no longer cancels against the image's DC level (frames with an offset of
+  // 10 and a deviation of 3 lose a factor 12 of the f32 sums' accuracy otherwise: the reference golden "n").
+  const float ctr = tile[TRr / 2][TCc / 2];
+  // horizontal pass: item = (staged row, run of kLcnHC output columns)
+  constexpr int CH = kLcnTW / kLcnHC, NT = kLcnHC + 2 * R;
+  for (int it = tid; it < TRr * CH; it += kLcnTW * kLcnRows) {
+    const int r = it / CH, c0 = (it - r * CH) * kLcnHC;
+    float v[NT], q[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      v[k] = tile[r][c0 + k] - ctr;
+      q[k] = v[k] * v[k];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) {
+      s1 += v[k];
+      s2 += q[k];
+    }
+    rs1[r][c0] = s1;
+    rs2[r][c0] = s2;
+#pragma unroll
+    for (int o = 1; o < kLcnHC; ++o) {
+      s1 = (s1 + v[o + NTAP - 1]) - v[o - 1];
+      s2 = (s2 + q[o + NTAP - 1]) - q[o - 1];
+      rs1[r][c0 + o] = s1;
+      rs2[r][c0 + o] = s2;
+    }
+  }
+  __syncthreads();
+  // vertical pass: a thread owns kLcnTH / kLcnRows consecutive output rows of its column
+  const int w = w_lo + tx;
+  constexpr int RPT = kLcnTH / kLcnRows, NV = RPT + 2 * R;
+  constexpr float cnt = (float)(NTAP * NTAP);
+  float c1[NV], c2[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    c1[k] = rs1[ty * RPT + k][tx];
+    c2[k] = rs2[ty * RPT + k][tx];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NTAP; ++k) {
+    s1 += c1[k];
+    s2 += c2[k];
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    if (i > 0) {
+      s1 = (s1 + c1[i + NTAP - 1]) - c1[i - 1];
+      s2 = (s2 + c2[i + NTAP - 1]) - c2[i - 1];
+    }
+    const int r = ty * RPT + i, h = h_lo + r;
+    if (w >= W || h >= H) continue;
+    const float avgs = s1 / cnt;
+    const float var = s2 / cnt - avgs * avgs + 1e-6f;
+    const float sd = sqrtf(var) + eps;
+    const float xv = tile[r + R][tx + R] - ctr;
+    const long o = base + (long)h * W + w;
+    y[o] = (xv - avgs) / sd;
+    stds[o] = sd;
+  }
+}
+
+int lcn_fast_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream) {
+  if (radius != 5) return CTD_ERR_UNSUPPORTED;                     // the radius the reference uses (exp_synph.py:41)
+  dim3 grid(ceil_div(W, kLcnTW), ceil_div(H, kLcnTH), N), block(kLcnTW, kLcnRows);
+  hipLaunchKernelGGL(lcn_fast_kernel<5>, grid, block, 0, stream, x, y, stds, H, W, eps);
+  CTD_LAUNCH_CHECK();
+  return CTD_OK;
+}
+
 int lcn_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream) {
   const int TRr = kLcnTH + 2 * radius, TCc = kLcnTW + 2 * radius;
   size_t lds = sizeof(double) * 2 * TRr * kLcnTW + sizeof(float) * (size_t)TRr * TCc;

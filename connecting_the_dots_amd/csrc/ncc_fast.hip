@@ -56,6 +56,10 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 constexpr int kSTW = 32, kSTH = 24, kSRows = 8;   // (A/B, rocprofv3, with the pattern job: 64 x 16: 36.9 us, 32 x 32: 35.1, 32 x 24: 34.0, 32 x 16: 37.1, 32 x 48: 39.4)
 constexpr double kDevFloor = 7e-2;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 2.1e-6 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
+#ifndef CTD_PREPASS_F32
+#define CTD_PREPASS_F32 1
+#endif
+constexpr bool kPrepassF32 = CTD_PREPASS_F32 != 0;   // block 9: f32 window sums on centred samples (see ncc_prepass_kernel)
 
 // out_mean = mean_scale * (window mean - cval), out_dev = 1 / sqrt(sum of squared deviations) (0: listed window), out_img = img - cval
 // (replicate border baked in), all laid out [image][H][W_out] with column x = xi + x_start;
@@ -83,7 +87,13 @@ struct PrepassJob {
 };
 
 // BSC > 0: compile-time block size (tap loops unrolled); BSC == 0: run-time `bs_rt`
-template <int BSC>
+// F32 (round 4, block 9): the window sums in f32 on samples CENTRED by the image's constant (the planes hold centred
+// values anyway): sum of squared deviations = s2' - s1' * mean', whose relative error is ~F * 2^-24 * (number of
+// roundings) with F = s2' / var = 1 + n (mean - centring)^2 / var -- the very factor the listing rule bounds by sqrt(8)
+// (windows above it are recomputed by the fix-up pass), so unlisted windows keep their reciprocal deviation to ~1e-6
+// relative, well inside the fast path's error budget; the raw mean for the flat-window test is mean' + centring.  Half the
+// LDS, no f32 -> f64 conversions, full-rate additions.
+template <int BSC, bool F32 = false>
 __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja, PrepassJob jb, int H, int W, int bs_rt,
                                                                    unsigned* __restrict__ clear_counters, int n_clear) {
   // the work-list counters of a ranked call (first used two kernels later): cleared here instead of by a memset launch
@@ -105,12 +115,13 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   if ((int)blockIdx.x * kSTW >= W_out) return;
   extern __shared__ double lds_d[];
   __shared__ double cred[1];
+  typedef typename std::conditional<F32, float, double>::type acc_t;
   const int bs = BSC > 0 ? BSC : bs_rt;
   const int half = bs / 2;
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
-  double* rs1 = lds_d;
-  double* rs2 = lds_d + TRr * kSTW;
-  float* tile = (float*)(lds_d + 2 * TRr * kSTW);
+  acc_t* rs1 = (acc_t*)lds_d;
+  acc_t* rs2 = rs1 + TRr * kSTW;
+  float* tile = (float*)(rs2 + TRr * kSTW);
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kSTW + tx;
   const int xi_lo = blockIdx.x * kSTW, h_lo = blockIdx.y * kSTH;
   const float* img = in + (long)img_idx * frame_stride;          // image = frame * C + channel
@@ -144,18 +155,19 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   __syncthreads();
   const double n = (double)(bs * bs), inv_n = 1.0 / n;
   const float cval = (float)(cred[0] / n);
+  const acc_t shift = F32 ? (acc_t)cval : (acc_t)0;                // F32: sums of the centred samples
   for (int r = ty; r < TRr; r += kSRows) {
     const float* row = tile + r * TCc + tx;
-    double s1 = 0, s2 = 0;
+    acc_t s1 = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < BSC; ++k) {
-      double v = (double)row[k];
+      acc_t v = (acc_t)row[k] - shift;
       s1 += v;
       s2 += v * v;
     }
     if (BSC == 0)
       for (int k = 0; k < bs; ++k) {
-        double v = (double)row[k];
+        acc_t v = (acc_t)row[k] - shift;
         s1 += v;
         s2 += v * v;
       }
@@ -167,19 +179,22 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
   for (int r = ty; r < kSTH; r += kSRows) {
     const int h = h_lo + r;
     if (xi >= W_out || h >= H) continue;
-    double s1 = 0, s2 = 0;
+    acc_t a1 = 0, a2 = 0;
 #pragma unroll
     for (int k = 0; k < BSC; ++k) {
-      s1 += rs1[(r + k) * kSTW + tx];
-      s2 += rs2[(r + k) * kSTW + tx];
+      a1 += rs1[(r + k) * kSTW + tx];
+      a2 += rs2[(r + k) * kSTW + tx];
     }
     if (BSC == 0)
       for (int k = 0; k < bs; ++k) {
-        s1 += rs1[(r + k) * kSTW + tx];
-        s2 += rs2[(r + k) * kSTW + tx];
+        a1 += rs1[(r + k) * kSTW + tx];
+        a2 += rs2[(r + k) * kSTW + tx];
       }
-    double mean = s1 * inv_n;
-    double var = s2 - s1 * mean;          // sum of squared deviations (sigma of ext.h:180-181)
+    // F32: a1, a2 are sums of centred samples -- mean = centred mean + centring, var is shift-invariant
+    const double s1 = (double)a1, s2 = (double)a2;
+    const double mean_c = F32 ? (double)(a1 * (acc_t)inv_n) : s1 * inv_n;     // mean of the summed samples
+    double var = F32 ? (double)(a2 - a1 * (acc_t)mean_c) : s2 - s1 * mean_c;  // sum of squared deviations (sigma of ext.h:180-181)
+    const double mean = F32 ? mean_c + (double)cval : mean_c;
     // Windows whose outputs the fast kernel cannot deliver within tolerance are listed for ncc_fixup_kernel
     // (see there), which recomputes EVERY output they take part in:
     //  * deviation small against the offset from the centring constant: cov = S_ab - n*ma*mb cancels in f32;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(kSTW* kSRows) void ncc_prepass_kernel(PrepassJob ja
     // A listed window's reciprocal deviation is stored as 0: the fast kernels then produce the placeholder score 0 for
     // exactly the outputs the fix-up pass overwrites (finite, so the in-kernel ranking's integer keys stay ordered;
     // what the ranking does about placeholders: see the all-D kernel).
-    const double mc = mean - (double)cval;
+    const double mc = F32 ? mean_c : mean - (double)cval;
     const bool flat = 4e-8 * n * mean * mean > var || var < kDevFloor * kDevFloor;
     const bool listed = flat || n * mc * mc > jp.flag_ratio * var;
     // reciprocal deviation (see ncc_inv_norm): v_rsq_f32 and one Newton step in f32, 1e-7 relative -- the f64 square
@@ -2364,12 +2379,14 @@ size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_f
 static int launch_prepass(const PrepassJob& ja, const PrepassJob& jb, int H, int W, int bs, const WorkList* work,
                           hipStream_t stream) {
   const int TRr = kSTH + bs - 1, TCc = kSTW + bs - 1;
-  size_t lds = sizeof(double) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
+  const bool f32 = bs == 9 && kPrepassF32;
+  size_t lds = (f32 ? sizeof(float) : sizeof(double)) * 2 * TRr * kSTW + sizeof(float) * (size_t)TRr * TCc;
   if (lds > 60 * 1024) return CTD_ERR_UNSUPPORTED;
   const int w_out = jb.nimg == 0 ? ja.W_out : (ja.nimg == 0 || jb.W_out > ja.W_out ? jb.W_out : ja.W_out);
   dim3 grid(ceil_div(w_out, kSTW), ceil_div(H, kSTH), ja.nimg + jb.nimg), block(kSTW, kSRows);
-  hipLaunchKernelGGL(bs == 9 ? ncc_prepass_kernel<9> : ncc_prepass_kernel<0>, grid, block, lds, stream, ja, jb, H, W, bs,
-                     work ? work->counters : nullptr, work ? work->parts : 0);
+  auto kern = ncc_prepass_kernel<0, false>;
+  if (bs == 9) kern = f32 ? ncc_prepass_kernel<9, true> : ncc_prepass_kernel<9, false>;
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, ja, jb, H, W, bs, work ? work->counters : nullptr, work ? work->parts : 0);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

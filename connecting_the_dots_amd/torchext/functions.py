@@ -343,10 +343,12 @@ def xcorrvol_argmax(in0, in1, n_disps, block_size, return_volume=False, algo=Non
 # LCN (reference: networks.LCN.tforward, model/networks.py:523-533 -- not part of the
 # reference's torchext; exposed here so the whole pre-normalisation is one kernel)
 # --------------------------------------------------------------------------------------
-def lcn(data, radius, epsilon):
+def lcn(data, radius, epsilon, algo=None):
     """data [N,1,H,W] f32 -> ((data - avg) / std, std), std = sqrt(E[x^2] - avg^2 + 1e-6) + epsilon,
     box statistics over a (2*radius+1)^2 reflect-padded window.  Not differentiable (the reference
-    only ever applies it to input images, exp_synph.py:84-91)."""
+    only ever applies it to input images, exp_synph.py:84-91).
+    algo (additive): 'exact' (default: f64 box sums, bit-identical to the oracle) | 'fast' (radius 5: f32 sliding sums,
+    within 1e-5 |b| + 1e-6 of 'exact' and of the reference -- whose own summation order is unspecified)."""
     _check(data, "data", (torch.float32,))
     if data.dim() != 4 or data.shape[1] != 1:
         raise RuntimeError("lcn expects [N,1,H,W]")
@@ -356,8 +358,11 @@ def lcn(data, radius, epsilon):
     dev = data.device
     y = torch.empty_like(data)
     std = torch.empty_like(data)
-    st = _lib.lib().ctd_lcn_f32(_ptr(data), _ptr(y), _ptr(std), N, H, W, int(radius), float(epsilon), dev.index,
-                                _stream(dev))
+    algo = algo or "exact"
+    if algo not in ("exact", "fast"):
+        raise RuntimeError("unknown algo %r" % (algo,))
+    fn = _lib.lib().ctd_lcn_fast_f32 if (algo == "fast" and int(radius) == 5) else _lib.lib().ctd_lcn_f32
+    st = fn(_ptr(data), _ptr(y), _ptr(std), N, H, W, int(radius), float(epsilon), dev.index, _stream(dev))
     _lib.check(st, "lcn")
     return y, std
 

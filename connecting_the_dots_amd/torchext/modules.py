@@ -30,13 +30,14 @@ class LCN(torch.nn.Module):
     """Local contrast normalisation with the constructor / call signature of the reference's
     `networks.LCN(radius, epsilon)` (model/networks.py:507-533); one fused HIP kernel."""
 
-    def __init__(self, radius, epsilon):
+    def __init__(self, radius, epsilon, algo=None):
         super().__init__()
         self.radius = radius
         self.epsilon = epsilon
+        self.algo = algo                  # additive: None / 'exact' (f64 box sums) | 'fast' (f32 sliding sums, radius 5)
 
     def forward(self, data):
-        return lcn(data.contiguous(), self.radius, self.epsilon)  # noqa: F405
+        return lcn(data.contiguous(), self.radius, self.epsilon, self.algo)  # noqa: F405
 
 
 class RectifiedPatternSimilarityLoss(torch.nn.Module):

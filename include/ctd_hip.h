@@ -188,6 +188,11 @@ int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_fra
  * -------------------------------------------------------------------------------------- */
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
                 float eps, int device, void* stream);
+/* tolerance-level variant (radius 5 only, else CTD_ERR_UNSUPPORTED): f32 sliding-window box sums instead of f64 ones;
+ * every output within 1e-5 |b| + 1e-6 of ctd_lcn_f32 and of the reference's networks.LCN (whose conv2d summation order
+ * is unspecified) */
+int ctd_lcn_fast_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
+                     float eps, int device, void* stream);
 
 /* Data-generation variant, data/lcn/lcn.pyx:16-58 (`lcn.normalize(img, kernel_size, epsilon)`): two-pass window mean
  * / std in f32 in the Cython loop's tap order (bit-identical), out = (x - mean) / (std + eps), out_std = raw std, a

@@ -42,6 +42,32 @@ def test_lcn_bit_exact_vs_oracle(te, oracle, shape):
     assert np.array_equal(y.cpu().numpy(), y0)
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 32), (1, 40, 53), (1, 432, 512), (2, 33, 65), (1, 31, 31), (3, 97, 34), (1, 11, 300)])
+def test_lcn_fast_within_tolerance(te, oracle, shape):
+    """algo='fast' (f32 sliding box sums, radius 5): every output within 1e-5 |b| + 1e-6 of the oracle, on uniform frames,
+    frames with a per-frame DC offset, and the reference's own goldens (the contract for the LCN is a tolerance: ATen's
+    conv2d summation order is unspecified)"""
+    N, H, W = shape
+    rs = np.random.RandomState(N * H + W)
+    for x in ((rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)).astype(np.float32), rs.rand(N, 1, H, W).astype(np.float32),
+              (rs.rand(N, 1, H, W) < 0.1).astype(np.float32)):
+        y0, s0 = oracle.lcn(x, 5, 0.05)
+        y, s = te.lcn(dev(x), 5, 0.05, algo="fast")
+        assert_close(s.cpu().numpy(), s0, what="fast std")
+        assert_close(y.cpu().numpy(), y0, what="fast lcn")
+
+
+def test_lcn_fast_vs_reference_golden(te):
+    g = golden("lcn_networks")
+    for k in range(2):
+        y, s = te.lcn(dev(g["x_%d" % k]), 5, 0.05, algo="fast")
+        assert_close(s.cpu().numpy(), g["std_%d" % k], what="std %d" % k)
+        assert_close(y.cpu().numpy(), g["y_%d" % k], rtol=2e-5, atol=2e-6, what="lcn %d" % k)
+    # other radii run the f64 kernel
+    y, s = te.LCN(2, 0.1, algo="fast")(dev(g["x_r2"]))
+    assert_close(s.cpu().numpy(), g["std_r2"], what="std r2")
+
+
 def test_lcn_errors(te):
     with pytest.raises(RuntimeError):
         te.lcn(torch.rand(1, 1, 8, 8), 2, 0.05)            # CPU tensor
