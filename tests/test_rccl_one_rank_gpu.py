@@ -41,6 +41,7 @@ def test_bench_n_gt_1_path_on_one_rccl_rank():
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(p.stdout.strip().splitlines()) == 1, "stdout carries more than the JSON line (RCCL's banner?): %r" % p.stdout[:300]
     j = json.loads(lines[0])
     cfg = j["config"]
     assert cfg["ranks_seen"] == 1 and "RCCL" in cfg["parallelism"] and "config 3" in cfg["workload"]
