@@ -160,22 +160,23 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
 // networks.LCN goldens and of the f64 kernel (tests/test_lcn_gpu.py); a sliding sum of at most 18 taps carries <= 14
 // roundings of the largest partial sum, 1e-7 relative on these positive sums.  Half the LDS (seven workgroups per CU).
 // ---------------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                    float* __restrict__ stds, int H, int W, float eps) {
-  constexpr int TRr = kLcnTH + 2 * R, TCc = kLcnTW + 2 * R, NTAP = 2 * R + 1;
-  __shared__ float rs1[TRr][kLcnTW], rs2[TRr][kLcnTW];            // row sums of x and x^2
+template <int R, int TW, int TH>
+__global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       float* __restrict__ stds, int H, int W, float eps) {
+  constexpr int ROWS = 256 / TW;                                   // thread rows of the block
+  constexpr int TRr = TH + 2 * R, TCc = TW + 2 * R, NTAP = 2 * R + 1;
+  __shared__ float rs1[TRr][TW], rs2[TRr][TW];                     // row sums of x and x^2
   __shared__ float tile[TRr][TCc];                                 // reflect-padded input
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int tid = ty * kLcnTW + tx;
-  const int w_lo = blockIdx.x * kLcnTW, h_lo = blockIdx.y * kLcnTH;
+  const int tid = threadIdx.x;
+  const int tx = tid % TW, ty = tid / TW;
+  const int w_lo = blockIdx.x * TW, h_lo = blockIdx.y * TH;
   const long base = (long)blockIdx.z * H * W;
   const float* xb = x + base;
-  for (int i0 = tid; i0 < TRr * TCc; i0 += kLcnTW * kLcnRows * 8) {
+  for (int i0 = tid; i0 < TRr * TCc; i0 += 256 * 8) {
     float t[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = min(i0 + kLcnTW * kLcnRows * u, TRr * TCc - 1);
+      const int i = min(i0 + 256 * u, TRr * TCc - 1);
       const int r = i / TCc, c = i - r * TCc;
       const int hh = reflect_idx(min(h_lo + r - R, H - 1 + R), H);
       const int ww = reflect_idx(min(w_lo + c - R, W - 1 + R), W);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float*
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (i0 + kLcnTW * kLcnRows * u < TRr * TCc) (&tile[0][0])[i0 + kLcnTW * kLcnRows * u] = t[u];
+      if (i0 + 256 * u < TRr * TCc) (&tile[0][0])[i0 + 256 * u] = t[u];
   }
   __syncthreads();
   // Everything below works on x - c, c = the tile's centre sample: (x - avg) / std and std do not change under a shift,
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float*
   // 10 and a deviation of 3 lose a factor 12 of the f32 sums' accuracy otherwise: the reference golden "n").
   const float ctr = tile[TRr / 2][TCc / 2];
   // horizontal pass: item = (staged row, run of kLcnHC output columns)
-  constexpr int CH = kLcnTW / kLcnHC, NT = kLcnHC + 2 * R;
-  for (int it = tid; it < TRr * CH; it += kLcnTW * kLcnRows) {
+  constexpr int CH = TW / kLcnHC, NT = kLcnHC + 2 * R;
+  for (int it = tid; it < TRr * CH; it += 256) {
     const int r = it / CH, c0 = (it - r * CH) * kLcnHC;
     float v[NT], q[NT];
 #pragma unroll
@@ -217,9 +218,10 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float*
     }
   }
   __syncthreads();
-  // vertical pass: a thread owns kLcnTH / kLcnRows consecutive output rows of its column
+  // vertical pass: a thread owns TH / ROWS consecutive output rows of its column
   const int w = w_lo + tx;
-  constexpr int RPT = kLcnTH / kLcnRows, NV = RPT + 2 * R;
+  constexpr int RPT = TH / ROWS, NV = RPT + 2 * R;
+  static_assert(TH % ROWS == 0 && 256 % TW == 0 && TW % kLcnHC == 0, "tile shape");
   constexpr float cnt = (float)(NTAP * NTAP);
   float c1[NV], c2[NV];
 #pragma unroll
@@ -251,10 +253,16 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_fast_kernel(const float*
   }
 }
 
+#ifndef CTD_LCN_FAST_TW
+#define CTD_LCN_FAST_TW 64   // (A/B, tools/time_lcn_variants.py, 16 x 432 x 512: 64 x 16 16.5 us, 32 x 32 16.9-17.9, 32 x 16 17.1-17.4, 64 x 8 17.8-18.0, 64 x 32 18.3-19.0, 32 x 64 19.1-19.3, 128 x 16 20.6, 128 x 8 22.1)
+#define CTD_LCN_FAST_TH 16
+#endif
+
 int lcn_fast_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream) {
   if (radius != 5) return CTD_ERR_UNSUPPORTED;                     // the radius the reference uses (exp_synph.py:41)
-  dim3 grid(ceil_div(W, kLcnTW), ceil_div(H, kLcnTH), N), block(kLcnTW, kLcnRows);
-  hipLaunchKernelGGL(lcn_fast_kernel<5>, grid, block, 0, stream, x, y, stds, H, W, eps);
+  constexpr int TW = CTD_LCN_FAST_TW, TH = CTD_LCN_FAST_TH;
+  dim3 grid(ceil_div(W, TW), ceil_div(H, TH), N), block(256);
+  hipLaunchKernelGGL((lcn_fast_kernel<5, TW, TH>), grid, block, 0, stream, x, y, stds, H, W, eps);
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

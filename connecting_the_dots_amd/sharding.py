@@ -68,6 +68,16 @@ def visible_gpu_count(kfd_nodes="/sys/class/kfd/kfd/topology/nodes"):
     return total
 
 
+def _device_count_in_child(timeout_s=120):
+    """torch.cuda.device_count() of a fresh interpreter (-1 when it cannot be had)."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             timeout=timeout_s)
+        return int(out.stdout.decode().strip().splitlines()[-1])
+    except Exception:                                   # noqa: BLE001
+        return -1
+
+
 def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
     """Start `n_ranks` fresh interpreters of `script` (one process per GPU; this parent does not load the HIP runtime
     -- it counts GPUs from the KFD topology -- and never re-execs), rendezvous on 127.0.0.1, relay rank 0's stdout while
@@ -77,8 +87,10 @@ def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
     import threading
     backend = os.environ.get("CTD_DIST_BACKEND", "nccl")
     n_dev = visible_gpu_count()
-    if n_dev < 0:                                       # no KFD topology to read (not a ROCm host): ask the runtime
-        n_dev = torch.cuda.device_count()
+    if n_dev < n_ranks and backend == "nccl":
+        # the topology says too few (or cannot be read: containers may hide it): before refusing, ask the runtime -- in a
+        # short-lived CHILD, so that this parent still never loads HIP
+        n_dev = max(n_dev, _device_count_in_child())
     err = check_gpu_count(n_ranks, backend, n_dev)
     if err:
         sys.stderr.write("%s: %s\n" % (os.path.basename(script), err))
