@@ -723,6 +723,11 @@ def main():
                 out["roofline"]["store_only_ceiling"].update({
                     "card_best_GBs": card_tbs * 1e3, "card_best_frac_of_peak": card_tbs * 1e3 / HBM_PEAK_GBS,
                     "card_best_pattern": card_pat, "kernel_frac_of_card_best": achieved / (card_tbs * 1e3)})
+        if workload == "config3":
+            out["config"]["scaling_note"] = ("the N = 1 line of this bench times config 2 (no geometric loss, no exchange); THIS "
+                                             "step's one-GPU time is `python bench.py --workload config3` (%s) -- weak-scaling "
+                                             "efficiency of config 3 = that time / this line's ms_per_step"
+                                             % ("0.525-0.535 ms on one MI355X, profiles/round4_config3_one_gpu.txt"))
         if geo is not None and n_exchanged[0]:
             last = ring[(n_exchanged[0] - 1) % len(ring)]
             if last[1] is not None:
