@@ -13,6 +13,11 @@ for case in range(cases):
     N = int(rs.randint(1, 5)); H = int(rs.randint(r + 1, 150)); W = int(rs.randint(r + 1, 300))
     x = torch.from_numpy((rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)).astype(np.float32)).cuda()
     y, s = te.lcn(x, r, 0.05)
+    if r == 5:                                               # algo='fast' against the f64 kernel, the suite's tolerance
+        yf, sf = te.lcn(x, r, 0.05, algo="fast")
+        if not bool(((yf - y).abs() <= y.abs() * 1e-5 + 1e-6).all() and ((sf - s).abs() <= s.abs() * 1e-5 + 1e-6).all()):
+            bad += 1
+            print("case %d N=%d H=%d W=%d: fast vs exact y %g std %g" % (case, N, H, W, float((yf - y).abs().max()), float((sf - s).abs().max())), flush=True)
     xd = x.double(); n = float((2 * r + 1) ** 2)
     p = F.pad(xd, (r, r, r, r), mode="reflect")
     k = torch.ones(1, 1, 2 * r + 1, 2 * r + 1, dtype=torch.float64, device="cuda")
