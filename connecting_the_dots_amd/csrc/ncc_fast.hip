@@ -53,7 +53,13 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 // pre-pass: (mean, sqrt(sum of squared deviations)) of the clamped bs x bs window centred
 // at the unclamped column x = xi + x_start, separable f64 sums through LDS.
 // ------------------------------------------------------------------------------------
-constexpr int kSTW = 32, kSTH = 24, kSRows = 8;   // (A/B, rocprofv3, with the pattern job: 64 x 16: 36.9 us, 32 x 32: 35.1, 32 x 24: 34.0, 32 x 16: 37.1, 32 x 48: 39.4)
+#ifndef CTD_PRE_TW
+// (A/B of the f32 kernel, tools/ab_tail.sh, frames only: 64 x 16 24.6 us, 64 x 12 25.3, 64 x 24 26.1, 32 x 24 26.7, 32 x 32 27.6,
+// 32 x 16 28.2, 128 x 16 28.3, 64 x 32 28.8, 128 x 8 30.0; the f64 kernel of rounds 1-3 preferred 32 x 24)
+#define CTD_PRE_TW 64
+#define CTD_PRE_TH 16
+#endif
+constexpr int kSTW = CTD_PRE_TW, kSTH = CTD_PRE_TH, kSRows = 256 / CTD_PRE_TW;   // (A/B, rocprofv3, with the pattern job: 64 x 16: 36.9 us, 32 x 32: 35.1, 32 x 24: 34.0, 32 x 16: 37.1, 32 x 48: 39.4)
 constexpr double kDevFloor = 7e-2;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 2.1e-6 (ncc_inv_norm)
 constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
 #ifndef CTD_PREPASS_F32

@@ -14,6 +14,7 @@ pat = torch.from_numpy(workloads.syn_dot_pattern(H, W, seed=42)[None, None]).cud
 x, _ = te.lcn(fr, 5, 0.05)
 p, _ = te.lcn(pat, 5, 0.05)
 p = p[0].contiguous()
-for _ in range(60):
-    te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast")
+prepared = te.prepare_pattern(p, N, D, 9)                # as the bench step: the pattern half of the pre-pass once
+for _ in range(200):
+    te.xcorrvol_argmax(x, p, D, 9, return_volume=True, algo="fast", prepared=prepared)
 torch.cuda.synchronize()
