@@ -33,6 +33,9 @@ SIGNATURES = {
     "ctd_xcorrvol_argmax_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "ctd_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 7 + [_c_float, _vp, _c_size_t,
                                                                                           _c_int, _vp]),
+    "ctd_lcn_xcorrvol_supported": (_c_int, [_c_int] * 5),
+    "ctd_lcn_xcorrvol_argmax_f32": (_c_int, [_vp, _vp, _vp, _c_int, _c_float, _c_int, _vp, _c_long, _vp, _vp, _vp] + [_c_int] * 6 +
+                                    [_c_float, _vp, _c_size_t, _c_int, _vp]),
     "ctd_photometric_fwd_f32": (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
     "ctd_photometric_fwd_f64": (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),
     "ctd_photometric_bwd_f32": (_c_int, [_vp, _vp, _vp, _vp] + [_c_int] * 6 + [_c_float, _c_int, _vp]),

@@ -1,6 +1,7 @@
 // ctd_api.hip -- the extern "C" surface declared in include/ctd_hip.h.
 // Argument validation lives here; kernels assume validated shapes.
 #include "ctd_internal.h"
+#include "ctd_prepass.h"
 #include "../../include/ctd_hip_bench.h"
 
 #include <deque>
@@ -50,7 +51,7 @@ void timing_end(hipStream_t stream, int columns) {
 
 extern "C" {
 
-int ctd_version(void) { return 4; }
+int ctd_version(void) { return 5; }
 
 void ctd_kernel_timing_enable(int enable) {
   g_timing = enable != 0;
@@ -233,6 +234,39 @@ int ctd_xcorrvol_argmax_f32(const float* in0, const float* in1, long in1_frame_s
                              workspace, workspace_bytes, /*counter_cleared=*/true, (hipStream_t)stream);
   }
   return CTD_ERR_INVALID_ARG;
+}
+
+int ctd_lcn_xcorrvol_supported(int H, int W, int D, int radius, int block_size) {
+  return vol_shape_ok(1, 1, H, W, D, block_size) && ncc_fast_rank_supported(1, H, W, D, block_size) &&
+                 lcn_stream_supported(H, W, radius, block_size) ? 1 : 0;
+}
+
+int ctd_lcn_xcorrvol_argmax_f32(const float* raw, float* lcn_out, float* std_out, int radius, float lcn_eps, int lcn_algo,
+                                const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx, float* best,
+                                int frames, int H, int W, int D, int block_size, int algo, float rerank_eps,
+                                void* workspace, size_t workspace_bytes, int device, void* stream) {
+  const bool prepared = (algo & CTD_PATTERN_PREPARED) != 0;
+  algo &= ~CTD_PATTERN_PREPARED;
+  if (algo != CTD_NCC_FAST || (lcn_algo != CTD_LCN_EXACT && lcn_algo != CTD_LCN_FAST)) return CTD_ERR_INVALID_ARG;
+  if (!vol_shape_ok(frames, 1, H, W, D, block_size) || in1_frame_stride < 0 || radius < 0 || rerank_eps != rerank_eps)
+    return CTD_ERR_INVALID_ARG;
+  if (frames == 0) return CTD_OK;
+  if (!raw || !lcn_out || !std_out || !in1 || !idx) return CTD_ERR_INVALID_ARG;
+  if (!ctd_lcn_xcorrvol_supported(H, W, D, radius, block_size) || ((uintptr_t)vol_out) % 16 != 0) return CTD_ERR_UNSUPPORTED;
+  DeviceGuard g(device);
+  if (g.status) return g.status;
+  const hipStream_t hs = (hipStream_t)stream;
+  const FusedLcn fused = {raw, std_out, radius, lcn_eps, lcn_algo == CTD_LCN_EXACT};
+  RankPlan rp;
+  rp.eps = rerank_eps < 0.f ? 0.f : rerank_eps;             // (as ctd_xcorrvol_argmax_f32 without a plain-argmax pass)
+  rp.idx = idx;
+  rp.best = best;
+  int st = ncc_fast_f32(lcn_out, in1, in1_frame_stride, vol_out, frames, 1, H, W, D, block_size, workspace, workspace_bytes,
+                        &rp, prepared, hs, &fused);           // streaming LCN + statistics, then the all-D kernel
+  if (st) return st;
+  st = ncc_fast_fixup_ranked(lcn_out, in1, in1_frame_stride, vol_out, frames, H, W, D, block_size, workspace, rp, rp.best, hs);
+  if (st) return st;
+  return rank_tail_f32(rp, vol_out, lcn_out, in1, in1_frame_stride, idx, rp.best, frames, D, H, W, block_size, hs);
 }
 
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius, float eps, int device,

@@ -44,9 +44,17 @@ size_t ncc_fast_workspace_bytes(int frames, int C, int H, int W, int D, int bs, 
 bool ncc_fast_rank_supported(int C, int H, int W, int D, int bs);
 size_t ncc_fast_rank_workspace_bytes(int frames, int H, int W, int D, bool per_frame_pattern);
 void ncc_fast_rank_offsets(int frames, int H, int W, int D, bool per_frame_pattern, size_t* off);
+// A fused call: the frames arrive raw and `in0` of ncc_fast_f32 is the buffer their LCN goes to (lcn_stream.hip).
+struct FusedLcn {
+  const float* raw;           // [frames][H][W] raw frames
+  float* stds;                // [frames][H][W] LCN deviation output (the LCN output itself is `in0`)
+  int radius;
+  float eps;
+  bool exact;                 // f64 box sums + the reference's f32 tail (the oracle's bits) | f32 sums, v_rcp / v_sqrt tail
+};
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, bool pattern_prepared,
-                 hipStream_t stream);
+                 hipStream_t stream, const FusedLcn* fused = nullptr);
 int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int frames, int C, int H, int W, int D, int bs,
                                  void* workspace, size_t workspace_bytes, hipStream_t stream);
 int ncc_fast_fixup_ranked(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int H, int W,

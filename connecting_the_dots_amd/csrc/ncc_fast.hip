@@ -31,8 +31,10 @@
 
 #include "ctd_internal.h"
 #include "ctd_ncc_point.h"
+#include "ctd_prepass.h"
 #include "ctd_rank.h"
 #include "ctd_tail.h"
+#include "ctd_wave.h"
 
 
 namespace ctd {
@@ -60,8 +62,7 @@ constexpr int kFDmaPerRow = 9; // LDS-DMA instructions the loader issues per row
 #define CTD_PRE_TH 16
 #endif
 constexpr int kSTW = CTD_PRE_TW, kSTH = CTD_PRE_TH, kSRows = 256 / CTD_PRE_TW;   // (A/B, rocprofv3, with the pattern job: 64 x 16: 36.9 us, 32 x 32: 35.1, 32 x 24: 34.0, 32 x 16: 37.1, 32 x 48: 39.4)
-constexpr double kDevFloor = 7e-2;     // windows with a smaller deviation are listed: keeps 1e-8 / (sa * sb) <= 2.1e-6 (ncc_inv_norm)
-constexpr double kFlagRatio = 1.8284;  // list a window when F - 1 = n*(mean - centring)^2 / (sum sq. dev.) > sqrt(8) - 1
+// kDevFloor, kFlagRatio (the listing rule's two constants): ctd_prepass.h
 #ifndef CTD_PREPASS_F32
 #define CTD_PREPASS_F32 1
 #endif
@@ -659,31 +660,12 @@ __device__ inline float lane_window_sum(float x, int lane) {
 // Vertical sum of BS rows: for BS == 9 the 3+3+3 tree (ring of 2 products + 6 triple
 // sums); other BS keep a ring of the last BS-1 products.
 // ------------------------------------------------------------------------------------
-typedef const void __attribute__((address_space(1))) * gptr_t;
-typedef void __attribute__((address_space(3))) * lptr_t;
-
-__device__ inline void dma_dword(const float* g, float* l) {   // LDS[l + 4*lane] <- *g (per-lane address)
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
-}
-__device__ inline void dma_quad(const float* g, float* l) {    // LDS[l + 16*lane .. +15] <- g[0..3] (16-byte aligned)
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
+// (dma_dword / dma_quad: ctd_wave.h)
 
 constexpr int gcd_ce(int a, int b) { return b == 0 ? a : gcd_ce(b, a % b); }
 constexpr int lcm_ce(int a, int b) { return a / gcd_ce(a, b) * b; }
 
-template <int N>
-__device__ inline void wait_vmcnt() {   // s_waitcnt vmcnt(N) only
-  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | 0x0070 | 0x0F00);
-}
-__device__ inline void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
-// raw s_barrier (no vmcnt drain, unlike __syncthreads) fenced against compiler motion of LDS accesses
-__device__ inline void wg_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
+// (wait_vmcnt / wait_lgkmcnt0 / wg_barrier: ctd_wave.h)
 
 template <int BS, bool ACCUM>
 __global__ __launch_bounds__(64 * (kFWaves + 1)) void ncc_fast_kernel(
@@ -898,26 +880,7 @@ __device__ inline void lds_read5(const float* arr, int lane, float (&o)[5]) {
   for (int k = 0; k < 5; ++k) o[k] = e[S + k];
 }
 
-// out[i] = prev_lane(sp[i]) + own + next_lane(pn[i]) for the lane's 4 columns: 8 v_add_f32_dpp.
-// Without bound_ctrl a lane whose shifted source does not exist (lane 0 for wave_shr, lane 63 for wave_shl) is
-// skipped by the hardware (its destination keeps the old value); with bound_ctrl:1 it reads 0, which is the
-// missing neighbour's contribution, so the three-operand form needs no preset moves.
-// One s_nop 1 covers the VALU-write -> DPP-read hazard of the operands (2 wait states).
-__device__ inline void window_combine4(const float (&sp)[4], float own, const float (&pn)[4], float (&o)[4]) {
-  // bound_ctrl:1 -- a lane whose shifted source does not exist reads 0: three-operand form, no preset moves
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %4, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %1, %5, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %2, %6, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %3, %7, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %0, %8, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %1, %9, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %2, %10, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %3, %11, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-      : "v"(sp[0]), "v"(sp[1]), "v"(sp[2]), "v"(sp[3]), "v"(pn[0]), "v"(pn[1]), "v"(pn[2]), "v"(pn[3]), "v"(own));
-}
+// (window_combine4: ctd_wave.h)
 
 template <int BS, bool ACCUM, bool VEC4, int WAVE>
 __device__ __forceinline__ void wide_consume(const float* lds, float* __restrict__ out, int f, int dg, int lane,
@@ -2563,8 +2526,9 @@ int ncc_fast_prepare_pattern_f32(const float* in1, long in1_frame_stride, int fr
 
 int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, float* out, int frames, int C, int H, int W,
                  int D, int bs, void* workspace, size_t workspace_bytes, RankPlan* rank, bool pattern_prepared,
-                 hipStream_t stream) {
+                 hipStream_t stream, const FusedLcn* fused) {
   if (bs < 2 || bs > 33) return CTD_ERR_UNSUPPORTED;
+  if (fused && (C != 1 || !lcn_stream_supported(H, W, fused->radius, bs))) return CTD_ERR_UNSUPPORTED;
   if (H >= (1 << 20) || W + D >= (1 << 19) || D > 512 || (long)frames * C >= (1 << 24)) return CTD_ERR_UNSUPPORTED;
   if (!out && !rank) return CTD_ERR_INVALID_ARG;
   if (rank && !ncc_fast_rank_supported(C, H, W, D, bs)) return CTD_ERR_UNSUPPORTED;
@@ -2601,7 +2565,22 @@ int ncc_fast_f32(const float* in0, const float* in1, long in1_frame_stride, floa
   const PrepassJob jb = {in1, (long)H * W, ws.bc, ws.m1, ws.v1, -ws.xoff, ws.W1,
                          pattern_prepared ? 0 : (per_frame ? frames : 1) * C, ws.counters + 1, ws.flag_b, -(bs - 1 - bs / 2), W,
                          ws.counters + 2, ws.run_rows, 1.0, kFlagRatio / C, ws.W1, 0, 0};
-  int st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
+  int st;
+  if (fused) {
+    // fused call: `in0` is the LCN OUTPUT buffer -- the streaming kernel (lcn_stream.hip) writes it and the frames'
+    // planes from the raw frames in one launch; the pattern's half (if not prepared) keeps the tiled kernel
+    const StatPlanes sp = {ws.ac, ws.m0, ws.v0, ws.Wp, 4, ws.counters, ws.flag_a, -(float)(bs * bs), (float)kFlagRatio};
+    st = lcn_stream_f32(fused->raw, const_cast<float*>(in0), fused->stds, frames, H, W, fused->eps, sp,
+                        rank ? rank->work.counters : nullptr, rank ? rank->work.parts : 0, fused->exact, stream);
+    if (st) return st;
+    if (!pattern_prepared) {
+      PrepassJob none = ja;
+      none.nimg = 0;
+      st = launch_prepass(none, jb, H, W, bs, nullptr, stream);
+    }
+  } else {
+    st = launch_prepass(ja, jb, H, W, bs, rank ? &rank->work : nullptr, stream);
+  }
   if (st) return st;
   switch (bs) {
     case 3: st = launch_fast<3>(in0, in1, in1_frame_stride, out, frames, C, H, W, D, ws, rank, stream); break;

@@ -367,6 +367,50 @@ def lcn(data, radius, epsilon, algo=None):
     return y, std
 
 
+def lcn_xcorrvol_argmax(raw, in1, n_disps, block_size, radius=5, epsilon=0.05, return_volume=False, lcn_algo="exact",
+                        rerank_eps=1e-5, prepared=None):
+    """Additive: `lcn` of the raw frames, then `xcorrvol_argmax(..., algo='fast')` against the (already LCN'd) pattern,
+    as ONE call whose first kernel streams the raw frames once and leaves both the LCN outputs and the matcher's window
+    statistics (ctd_lcn_xcorrvol_argmax_f32).  raw [N,1,H,W]; in1 [1,H,W] | [N,1,H,W].
+    Returns (lcn, std, idx, best[, volume]).  lcn_algo 'exact': lcn / std carry the bits of `lcn(..., algo='exact')`;
+    'fast': f32 box sums, tolerance level on well-conditioned windows only (see include/ctd_hip.h).
+    Shapes the fused kernel does not cover run the two calls it replaces."""
+    _check(raw, "raw", (torch.float32,))
+    _check(in1, "in1", (torch.float32,))
+    if raw.dim() != 4 or raw.shape[1] != 1 or in1.dim() not in (3, 4):
+        raise RuntimeError("lcn_xcorrvol_argmax expects raw [N,1,H,W] and in1 [1,H,W] or [N,1,H,W]")
+    if lcn_algo not in ("exact", "fast"):
+        raise RuntimeError("unknown lcn_algo %r" % (lcn_algo,))
+    L = _lib.lib()
+    dev = _same_device(raw, in1)
+    N, C, H, W = raw.shape
+    if tuple(in1.shape[-3:]) != (C, H, W):
+        raise RuntimeError("raw and in1 must have the same [C,H,W] shape")
+    D, bs = int(n_disps), int(block_size)
+    if not (0 <= int(radius) < min(H, W)):
+        raise RuntimeError("lcn: radius must be smaller than the image (ReflectionPad2d rule)")
+    if not L.ctd_lcn_xcorrvol_supported(H, W, D, int(radius), bs):
+        y, std = lcn(raw, radius, epsilon, algo=lcn_algo)
+        out = xcorrvol_argmax(y, in1, D, bs, return_volume=return_volume, algo="fast", rerank_eps=rerank_eps, prepared=prepared)
+        return (y, std) + tuple(out)
+    stride1 = 0 if in1.dim() == 3 else C * H * W
+    y, std = torch.empty_like(raw), torch.empty_like(raw)
+    idx = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+    best = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    vol = torch.empty((N, D, H, W), dtype=torch.float32, device=dev) if return_volume else None
+    a = 1
+    if prepared is not None:
+        _check_prepared(prepared, "lcn_xcorrvol_argmax", a, in1, N, D, bs, dev)
+        ws, a = prepared.workspace, a | 0x100                        # CTD_PATTERN_PREPARED
+    else:
+        ws = _workspace(L.ctd_xcorrvol_argmax_workspace_bytes(N, C, H, W, D, bs, a), dev)
+    st = L.ctd_lcn_xcorrvol_argmax_f32(_ptr(raw), _ptr(y), _ptr(std), int(radius), float(epsilon),
+                                       0 if lcn_algo == "exact" else 1, _ptr(in1), stride1, _ptr(vol), _ptr(idx), _ptr(best),
+                                       N, H, W, D, bs, a, float(rerank_eps), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(st, "lcn_xcorrvol_argmax")
+    return (y, std, idx, best, vol) if return_volume else (y, std, idx, best)
+
+
 def lcn_normalize(img, kernel_size=4, epsilon=0.01):
     """Additive: the data generator's LCN, `lcn.normalize(img, kernel_size, epsilon)` of data/lcn/lcn.pyx:16-58
     (two-pass mean / std, zero border of width kernel_size, returns (lcn, raw std)); img [H,W] or [N,H,W]."""

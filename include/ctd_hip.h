@@ -38,7 +38,7 @@ enum ctd_status {
   CTD_ERR_HIP = 1000           /* 1000 + hipError_t of the failing runtime call           */
 };
 
-int ctd_version(void);                       /* ABI version, currently 4 (4: ctd_costvol_fast_f32 takes a workspace, ctd_costvol_workspace_bytes; 2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
+int ctd_version(void);                       /* ABI version, currently 5 (5: + ctd_lcn_xcorrvol_argmax_f32 / ctd_lcn_xcorrvol_supported; 4: ctd_costvol_fast_f32 takes a workspace, ctd_costvol_workspace_bytes; 2: ranked argmax inside the all-D volume kernel, its workspace is ctd_xcorrvol_argmax_workspace_bytes(); 3: + ctd_xcorrvol_pattern_prepare_f32 / CTD_PATTERN_PREPARED, ctd_geometric_sym_fwd_f32) */
 const char* ctd_status_string(int status);
 
 /* (Bench instrumentation -- per-kernel device timing of the volume kernel -- is declared in ctd_hip_bench.h: it is not
@@ -193,6 +193,32 @@ int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, i
  * is unspecified) */
 int ctd_lcn_fast_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
                      float eps, int device, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * LCN of the frames + NCC volume + argmax over disparity in one call (C == 1): the step
+ *   ir = LCN(raw)  (model/networks.py:507-533, applied to the input images at model/exp_synph.py:84-91)
+ *   vol = xcorrvol(ir, pattern)  (ext_cuda.cpp:73-86);  idx = argmax_d vol
+ * of a matcher built on the reference's ops, without the round trip of the LCN output through memory before the
+ * matcher's window statistics: one streaming kernel (a wavefront per 232-column strip and band of rows) reads the raw
+ * frames once and writes lcn_out, std_out and the frame-side planes of the fast NCC path.
+ *   raw [frames][1][H][W] -> lcn_out, std_out [frames][1][H][W] (both required);  in1 = the LCN'd pattern, as for
+ *   ctd_xcorrvol_argmax_f32, whose remaining arguments, outputs, workspace and CTD_PATTERN_PREPARED rule apply unchanged
+ *   (algo = CTD_NCC_FAST [| CTD_PATTERN_PREPARED]).
+ * lcn_algo: CTD_LCN_EXACT -- f64 box sums and the reference's f32 elementwise tail: lcn_out / std_out carry the bits of
+ *   ctd_lcn_f32 (f64 sums of f32 samples are exact in any order unless one window spans more than 2^29 in magnitude);
+ *   CTD_LCN_FAST -- f32 sums of samples centred by one constant per wavefront, v_rcp / v_sqrt tail: tolerance level,
+ *   and only for windows whose variance is not small against their mean square (an f32 one-pass variance cannot do
+ *   better: E[x^2] - avg^2 cancels; the reference's own f32 conv2d has the same limit).
+ * Supported where ctd_lcn_xcorrvol_supported() says so (radius 5, block 9, W % 4 == 0, W >= 16, H >= 11 and the ranked
+ * fast path of ctd_xcorrvol_rank_supported()); CTD_ERR_UNSUPPORTED otherwise (call ctd_lcn_f32 + ctd_xcorrvol_argmax_f32).
+ * -------------------------------------------------------------------------------------- */
+#define CTD_LCN_EXACT 0
+#define CTD_LCN_FAST 1
+int ctd_lcn_xcorrvol_supported(int H, int W, int D, int radius, int block_size);
+int ctd_lcn_xcorrvol_argmax_f32(const float* raw, float* lcn_out, float* std_out, int radius, float lcn_eps, int lcn_algo,
+                                const float* in1, long in1_frame_stride, float* vol_out, int64_t* idx, float* best,
+                                int frames, int H, int W, int D, int block_size, int algo, float rerank_eps,
+                                void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* Data-generation variant, data/lcn/lcn.pyx:16-58 (`lcn.normalize(img, kernel_size, epsilon)`): two-pass window mean
  * / std in f32 in the Cython loop's tap order (bit-identical), out = (x - mean) / (std + eps), out_std = raw std, a

@@ -36,7 +36,7 @@ def test_ctypes_table_matches_header():
     # the measurement hooks live in a header of their own, outside the drop-in interface
     assert sorted(_lib.BENCH_SIGNATURES) == declared_symbols(BENCH_HEADER)
     assert not any("timing" in n for n in declared_symbols())
-    assert _lib.lib().ctd_version() == 4
+    assert _lib.lib().ctd_version() == 5
     assert _lib.lib().ctd_status_string(1) == b"invalid argument"
 
 
