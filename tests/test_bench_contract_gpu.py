@@ -41,11 +41,23 @@ def test_single_gpu_line():
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
     assert len(j["repeat_ms_per_step"]) == 2 and j["settle_steps"] >= 20
     assert {"volume_kernel_alone", "fused_volume_free"} <= set(j["also_measured"])
+    # the second region (config 3's step) at the same N, like for like with the N > 1 lines
+    c3 = j["config3"]
+    assert "config 3" in c3["workload"] and c3["steps"] == 4 and c3["ms_per_step"] > j["ms_per_step"] * 0.9
+    assert abs(c3["value"] - units / (c3["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * c3["value"]
+    assert len(c3["loss_allgather"]) == 1 and c3["loss_allgather"][0] == c3["loss_allgather"][0]
+    # end-to-end index parity of the timed step from the raw frame through the exact LCN: reported, near-ties only
+    e2e = j["disparity_mae_detail"]["timed_workload_frame0_vs_exact_lcn_pipeline"]
+    assert e2e["pixels"] == 432 * 512 and e2e["pixels_differing"] <= 8 and "scaling_note" not in cfg
 
 
 def test_two_ranks_self_launched_over_gloo():
     j = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", env={"CTD_DIST_BACKEND": "gloo"})
-    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and "config 3" in j["config"]["workload"]
-    assert len(j["config"]["loss_allgather"]) == 2 and all(v == v for v in j["config"]["loss_allgather"])
+    # the headline is the SAME config-2 step as at N = 1 (no collective in it); config 3 is the second block
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and "config 2" in j["config"]["workload"]
     units = 2 * 16 * 432 * 512 * 128
     assert abs(j["value"] - units / (j["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * j["value"]
+    c3 = j["config3"]
+    assert "config 3" in c3["workload"] and "gloo" in c3["parallelism"]
+    assert len(c3["loss_allgather"]) == 2 and all(v == v for v in c3["loss_allgather"])
+    assert abs(c3["value"] - units / (c3["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * c3["value"]

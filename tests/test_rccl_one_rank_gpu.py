@@ -34,7 +34,7 @@ def _env():
 
 
 def test_bench_n_gt_1_path_on_one_rccl_rank():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "config3",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist",
                         "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=_env(),
                        timeout=600, cwd=ROOT)
     _save_log("rccl_one_rank_bench.log", p.stdout + "\n--- stderr ---\n" + p.stderr[-6000:])
@@ -43,12 +43,15 @@ def test_bench_n_gt_1_path_on_one_rccl_rank():
     assert len(lines) == 1, p.stdout[-2000:]
     assert len(p.stdout.strip().splitlines()) == 1, "stdout carries more than the JSON line (RCCL's banner?): %r" % p.stdout[:300]
     j = json.loads(lines[0])
-    cfg = j["config"]
-    assert cfg["ranks_seen"] == 1 and "RCCL" in cfg["parallelism"] and "config 3" in cfg["workload"]
-    assert len(cfg["loss_allgather"]) == 1 and cfg["loss_allgather"][0] == cfg["loss_allgather"][0]      # gathered, finite
+    cfg, c3 = j["config"], j["config3"]
+    # both blocks: the config-2 headline (no collective) and config 3 with its all-gather over RCCL
+    assert cfg["ranks_seen"] == 1 and "config 2" in cfg["workload"]
+    assert "RCCL" in c3["parallelism"] and "config 3" in c3["workload"]
+    assert len(c3["loss_allgather"]) == 1 and c3["loss_allgather"][0] == c3["loss_allgather"][0]      # gathered, finite
     assert j["n_gpus"] == 1 and j["disparity_mae_vs_ref"] == 0.0
     units = 16 * 432 * 512 * 128
     assert abs(j["value"] - units / (j["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * j["value"]
+    assert abs(c3["value"] - units / (c3["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * c3["value"]
 
 
 def test_track_trainer_ddp_on_one_rccl_rank(tmp_path):
