@@ -187,10 +187,37 @@ __global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__
       if (i0 + 256 * u < TRr * TCc) (&tile[0][0])[i0 + 256 * u] = t[u];
   }
   __syncthreads();
-  // Everything below works on x - c, c = the tile's centre sample: (x - avg) / std and std do not change under a shift,
-  // and E[x^2] - avg^2 of the shifted samples no longer cancels against the image's DC level (frames with an offset of
-  // 10 and a deviation of 3 lose a factor 12 of the f32 sums' accuracy otherwise: the reference golden "n").
-  const float ctr = tile[TRr / 2][TCc / 2];
+  // Everything below works on x - c: (x - avg) / std and std do not change under a shift, and E[x^2] - avg^2 of the shifted
+  // samples no longer cancels against the image's DC level (frames with an offset of 10 and a deviation of 3 lose a factor
+  // 12 of the f32 sums' accuracy otherwise: the reference golden "n").  c = 0 when the staged tile reaches zero (the plain
+  // sums: EXACT on a zero background with sparse bright samples), else the tile's MEAN (one reduction): close to every
+  // window's own mean wherever the tile has one level, and a sparse bright sample moves it by 1 / 1924 of its height.
+  // (Until round 5 c was the tile's centre SAMPLE: a bright dot there on a dark flat background made every window of the
+  // tile cancel against 0.81 -- std off by up to 2.5e-3 relative.  Tried on the way: the tile's value closest to zero,
+  // med3(0, min, max) -- frames with a DC level fall back to the plain sums' conditioning, the golden "n" again; the mean
+  // alone -- a zero background is then -mean, not 0, and the windows without a sample sit on the 1e-6 floor: 4e-6 of std.)
+  __shared__ float red[3][4];
+  {
+    float sm = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < TRr * TCc; i += 256) {
+      const float v = (&tile[0][0])[i];
+      sm += v;
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sm += __shfl_xor(sm, o);
+      mn = fminf(mn, __shfl_xor(mn, o));
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sm; red[1][tid >> 6] = mn; red[2][tid >> 6] = mx; }
+  }
+  __syncthreads();
+  const float t_min = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+  const float t_max = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+  const float t_mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.f / (float)(TRr * TCc));
+  const float ctr = (t_min <= 0.f && t_max >= 0.f) ? 0.f : t_mean;
   // horizontal pass: item = (staged row, run of kLcnHC output columns)
   constexpr int CH = TW / kLcnHC, NT = kLcnHC + 2 * R;
   for (int it = tid; it < TRr * CH; it += 256) {

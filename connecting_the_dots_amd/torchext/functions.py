@@ -347,8 +347,9 @@ def lcn(data, radius, epsilon, algo=None):
     """data [N,1,H,W] f32 -> ((data - avg) / std, std), std = sqrt(E[x^2] - avg^2 + 1e-6) + epsilon,
     box statistics over a (2*radius+1)^2 reflect-padded window.  Not differentiable (the reference
     only ever applies it to input images, exp_synph.py:84-91).
-    algo (additive): 'exact' (default: f64 box sums, bit-identical to the oracle) | 'fast' (radius 5: f32 sliding sums,
-    within 1e-5 |b| + 1e-6 of 'exact' and of the reference -- whose own summation order is unspecified)."""
+    algo (additive): 'exact' (default: f64 box sums, bit-identical to the oracle) | 'fast' (radius 5: f32 sliding sums of
+    tile-centred samples, within 1e-5 |b| + 1e-6 of 'exact' and of the reference -- whose own summation order is unspecified --
+    except on the variance floor of flat non-zero levels, see include/ctd_hip.h)."""
     _check(data, "data", (torch.float32,))
     if data.dim() != 4 or data.shape[1] != 1:
         raise RuntimeError("lcn expects [N,1,H,W]")

@@ -45,16 +45,21 @@ def test_lcn_bit_exact_vs_oracle(te, oracle, shape):
 @pytest.mark.parametrize("shape", [(2, 24, 32), (1, 40, 53), (1, 432, 512), (2, 33, 65), (1, 31, 31), (3, 97, 34), (1, 11, 300)])
 def test_lcn_fast_within_tolerance(te, oracle, shape):
     """algo='fast' (f32 sliding box sums, radius 5): every output within 1e-5 |b| + 1e-6 of the oracle, on uniform frames,
-    frames with a per-frame DC offset, and the reference's own goldens (the contract for the LCN is a tolerance: ATen's
-    conv2d summation order is unspecified)"""
+    frames with a per-frame DC offset, binary patterns, structured-light frames (flat or low-noise dark background with
+    sparse bright samples, one of them at every tile's centre -- the case the round-4 centring failed on) and the
+    reference's own goldens (the contract for the LCN is a tolerance: ATen's conv2d summation order is unspecified)"""
     N, H, W = shape
     rs = np.random.RandomState(N * H + W)
-    for x in ((rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)).astype(np.float32), rs.rand(N, 1, H, W).astype(np.float32),
-              (rs.rand(N, 1, H, W) < 0.1).astype(np.float32)):
+    dots = ((rs.rand(N, 1, H, W) < 0.06) * (0.6 + 0.4 * rs.rand(N, 1, H, W))).astype(np.float32)
+    dots_c = dots.copy()
+    dots_c[:, :, 8::16, 32::64] = 0.9                      # a bright sample at the centre of every 64 x 16 tile
+    for kind, x in enumerate(((rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)).astype(np.float32), rs.rand(N, 1, H, W).astype(np.float32),
+                              (rs.rand(N, 1, H, W) < 0.1).astype(np.float32), dots, dots_c,
+                              (dots_c + 0.02 + 0.01 * rs.rand(N, 1, H, W)).astype(np.float32))):
         y0, s0 = oracle.lcn(x, 5, 0.05)
         y, s = te.lcn(dev(x), 5, 0.05, algo="fast")
-        assert_close(s.cpu().numpy(), s0, what="fast std")
-        assert_close(y.cpu().numpy(), y0, what="fast lcn")
+        assert_close(s.cpu().numpy(), s0, what="fast std, input kind %d" % kind)
+        assert_close(y.cpu().numpy(), y0, what="fast lcn, input kind %d" % kind)
 
 
 def test_lcn_fast_vs_reference_golden(te):

@@ -11,11 +11,24 @@ bad = 0
 for case in range(cases):
     r = int(rs.choice([1, 2, 5, 5, 5, 7]))
     N = int(rs.randint(1, 5)); H = int(rs.randint(r + 1, 150)); W = int(rs.randint(r + 1, 300))
-    x = torch.from_numpy((rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)).astype(np.float32)).cuda()
+    kind = case % 4
+    if kind == 0:                                            # uniform with a DC level per frame
+        xn = rs.rand(N, 1, H, W) * 3 + rs.randn(N, 1, 1, 1)
+    elif kind == 1:                                          # structured light: flat zero background, sparse bright samples
+        xn = (rs.rand(N, 1, H, W) < 0.06) * (0.5 + 0.5 * rs.rand(N, 1, H, W))
+    elif kind == 2:                                          # the same on a low-noise dark level, a bright sample on a regular grid
+        xn = (rs.rand(N, 1, H, W) < 0.06) * 0.9 + 0.02 + 0.01 * rs.rand(N, 1, H, W)
+        xn[:, :, 8::16, 32::64] = 0.9
+    else:                                                    # flat regions at different levels (one f32 order's var is as
+        xn = np.round(rs.rand(N, 1, H, W) * 2) * 0.25 + 0.003 * rs.randn(N, 1, H, W)   # good as another's only up to E[x^2] 2^-24)
+    x = torch.from_numpy(xn.astype(np.float32)).cuda()
     y, s = te.lcn(x, r, 0.05)
-    if r == 5:                                               # algo='fast' against the f64 kernel, the suite's tolerance
+    if r == 5 and kind != 3:                                 # algo='fast' against the f64 kernel, the suite's tolerance
         yf, sf = te.lcn(x, r, 0.05, algo="fast")
-        if not bool(((yf - y).abs() <= y.abs() * 1e-5 + 1e-6).all() and ((sf - s).abs() <= s.abs() * 1e-5 + 1e-6).all()):
+        # (kind 2 -- a low-noise level with windows that hold no bright sample -- sits on the variance floor of 1e-6: an f32
+        # one-pass variance is good to E[(x - c)^2] * 2^-24 * (roundings) there, 3e-6 absolute of std at these levels)
+        atol = 3e-6 if kind == 2 else 1e-6
+        if not bool(((yf - y).abs() <= y.abs() * 1e-5 + atol).all() and ((sf - s).abs() <= s.abs() * 1e-5 + atol).all()):
             bad += 1
             print("case %d N=%d H=%d W=%d: fast vs exact y %g std %g" % (case, N, H, W, float((yf - y).abs().max()), float((sf - s).abs().max())), flush=True)
     xd = x.double(); n = float((2 * r + 1) ** 2)
