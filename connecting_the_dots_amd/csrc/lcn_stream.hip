@@ -403,10 +403,12 @@ int lcn_stream_f32(const float* x, float* y, float* stds, int N, int H, int W, f
   a.N = N; a.H = H; a.W = W; a.eps = eps;
   a.n_strips = ceil_div(W, kLsValid);
   // one workgroup (three wavefronts) per (strip, band, frame); every band pays 18 warm-up rows, and four workgroups per
-  // CU are resident side by side on its four SIMDs: as many bands as give at most 1024 workgroups (A/B at config 2,
+  // CU are resident side by side on its four SIMDs: as many bands as give at most 4 x CUs workgroups (A/B at config 2,
   // rocprofv3, f32 sums: 768 workgroups 33.9 us, 864 32.5, 960 / 1008 31.4, 1152 38.0, 1280 38.2)
-  int target = 1024;
-  if (const char* e = getenv("CTD_LS_WAVES")) target = atoi(e);          // (experiment knob)
+  int target = 1024, dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+    target = 4 * n_cu;
+  if (const char* e = getenv("CTD_LS_WAVES")) target = atoi(e);          // (experiment knob of tools/r5_prof_fused.sh)
   int n_bands = target / (N * a.n_strips);
   if (n_bands > H / 8) n_bands = H / 8;
   if (n_bands < 1) n_bands = 1;

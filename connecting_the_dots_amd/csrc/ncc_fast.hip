@@ -2284,7 +2284,35 @@ struct AlldPlan {
 };
 // `ranked`: the workgroup keeps the ranking of its pixels in LDS (band height limited by the slots, every disparity in one
 // workgroup).  Otherwise the band may be as tall as the image and the passes may be split over workgroups.
+// compute units of the current device (the plan's cost model counts rounds of one workgroup per CU); asked once per device
+static int device_cu_count() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    cus[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+  }
+  return cus[dev];
+}
+
+static AlldPlan alld_plan_compute(int frames, int H, int W, int D, bool ranked, int n_cu);
+// (the unranked plan tries every band height for every pass split: ~5 K candidates at 1024 x 1024 x 256, on the launch path
+// of a sub-millisecond call -- the last few shapes' plans are kept; a plan is a pure function of its key)
 static AlldPlan alld_plan(int frames, int H, int W, int D, bool ranked = true) {
+  struct Key { int frames, H, W, D, ranked, n_cu; AlldPlan plan; };
+  static thread_local Key cache[8];
+  static thread_local int next = 0;
+  const int n_cu = device_cu_count();
+  for (const Key& k : cache)
+    if (k.frames == frames && k.H == H && k.W == W && k.D == D && k.ranked == (int)ranked && k.n_cu == n_cu && k.frames > 0) return k.plan;
+  Key& k = cache[next];
+  next = (next + 1) % 8;
+  k = Key{frames, H, W, D, (int)ranked, n_cu, alld_plan_compute(frames, H, W, D, ranked, n_cu)};
+  return k.plan;
+}
+
+static AlldPlan alld_plan_compute(int frames, int H, int W, int D, bool ranked, int n_cu) {
   AlldPlan ap;
   ap.n_psplit = 1;
   // The disparities are dealt evenly over the ceil(D / 30) passes (D = 128: 5 x 26 on 13 wavefronts).  Four full passes
@@ -2305,7 +2333,7 @@ static AlldPlan alld_plan(int frames, int H, int W, int D, bool ranked = true) {
     for (int rows = max_rows; rows >= 4; --rows) {
       if (rows > H) continue;
       const long wgs = base * ceil_div(H, rows);
-      const double cost = (double)((wgs + 255) / 256) * (double)(ceil_div(rows + 8, 6) * 6) * (cr == 2 ? kTwoRowPenalty : 1.0);
+      const double cost = (double)((wgs + n_cu - 1) / n_cu) * (double)(ceil_div(rows + 8, 6) * 6) * (cr == 2 ? kTwoRowPenalty : 1.0);
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; ap.chunk_rows = cr; }
     }
   }
@@ -2318,7 +2346,7 @@ static AlldPlan alld_plan(int frames, int H, int W, int D, bool ranked = true) {
       if (ceil_div(ap.n_pass, ppg) != sp) continue;                // (the same passes per workgroup with fewer workgroups)
       for (int rows = H; rows >= 4; --rows) {
         const long wgs = base * ceil_div(H, rows) * sp;
-        const double cost = (double)((wgs + 255) / 256) * ppg * (double)(ceil_div(rows + 8, 6) * 6);
+        const double cost = (double)((wgs + n_cu - 1) / n_cu) * ppg * (double)(ceil_div(rows + 8, 6) * 6);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; ap.band_rows = rows; ap.n_psplit = sp; }
       }
     }

@@ -87,10 +87,13 @@ def launch_ranks(script, argv, n_ranks, deadline_s=None, capture_rank0=True):
     import threading
     backend = os.environ.get("CTD_DIST_BACKEND", "nccl")
     n_dev = visible_gpu_count()
-    if n_dev < n_ranks and backend == "nccl":
-        # the topology says too few (or cannot be read: containers may hide it): before refusing, ask the runtime -- in a
-        # short-lived CHILD, so that this parent still never loads HIP
-        n_dev = max(n_dev, _device_count_in_child())
+    if backend == "nccl" and n_ranks > 1:
+        # the topology lists every GPU of the host even where a device cgroup lets this container open fewer, and it may
+        # be unreadable altogether: the count that decides is the runtime's -- asked in a short-lived CHILD, so that this
+        # parent still never loads HIP.  (One rank needs no second opinion.)
+        n_child = _device_count_in_child()
+        if n_child >= 0:
+            n_dev = n_child if n_dev < n_ranks else min(n_dev, n_child)
     err = check_gpu_count(n_ranks, backend, n_dev)
     if err:
         sys.stderr.write("%s: %s\n" % (os.path.basename(script), err))
@@ -189,9 +192,11 @@ def reduce_ratio_ddp(numerator, denominator, group=None):
     single-process batch.  Value: the global ratio on every rank (what the reference logs); the denominator carries
     no gradient (in the reference it is the LCN std of the input, or a sample count)."""
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        # one process: the reference's plain division (networks.py:377), bit for bit where the denominator is positive --
+        # a multiply by 1 / d rounds differently -- and a zero term (value and gradient) where it is not
         d1 = denominator.reshape(()).detach()
-        return numerator.reshape(()) * torch.where(d1 > 0, 1.0 / torch.where(d1 > 0, d1, torch.ones_like(d1)),
-                                                   torch.zeros_like(d1))
+        ok = d1 > 0
+        return numerator.reshape(()) / torch.where(ok, d1, torch.ones_like(d1)) * ok.to(d1.dtype)
     world = dist.get_world_size(group)
     local = torch.stack([numerator.reshape(()), denominator.reshape(())]).detach()
     total = local.clone()

@@ -175,7 +175,9 @@ int ctd_costvol_f32(const float* im, const float* pattern, long pattern_frame_st
  * SAD / MSE with block 9 and W % 4 == 0 are evaluated as a replicate-border 9 x 9 box filter of the per-pixel plane
  * |P[r][clamp(c - d)] - I[r][c]| (one subtract per output instead of 81) by the NCC volume kernel's pipeline; that path
  * needs `workspace` (ctd_costvol_workspace_bytes(), 16-byte aligned; 0 bytes / NULL: the LDS-tiled 81-tap kernel runs
- * instead).  The census types use the census-transform kernel and no workspace.  (Signature since ABI version 4.) */
+ * instead).  The census types use the census-transform kernel and no workspace.  (Signature since ABI version 4.)
+ * pattern_frame_stride: 0 (one pattern for all frames) or H * W (dense per-frame patterns); anything else is
+ * CTD_ERR_INVALID_ARG here -- ctd_costvol_f32 takes arbitrary strides. */
 size_t ctd_costvol_workspace_bytes(int frames, int H, int W, int D, int block_size, int type, int per_frame_pattern);
 int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_frame_stride, float* cost,
                     int frames, int H, int W, int D, int block_size, int type, float eps,
