@@ -12,7 +12,7 @@ tag=${1:-round2}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --headline-only"
+B="python bench.py --headline-only --workload config2"
 # 1. kernel trace of the exact bench command (no PMC in this pass)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 20 --warmup 3 > $out/bench_under_rocprof.log 2>&1 || exit 1
 grep '^{"metric"' $out/bench_under_rocprof.log > $out/${tag}_bench_under_rocprof.json
