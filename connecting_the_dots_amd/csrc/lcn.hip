@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kLcnTW* kLcnRows) void lcn_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Tolerance-level variant (`algo = 'fast'`, radius 5): the same tile, the box sums in F32 as sliding windows -- the first
+// Tolerance-level variant (`algo = 'fast'`, radius 1 .. 7): the same tile, the box sums in F32 as sliding windows -- the first
 // output of a run is a fresh 11-term sum, each next one adds the entering and subtracts the leaving tap (3 additions per
 // output and pass instead of 11 half-rate f64 ones), runs of 8 columns / 4 rows.  The contract for the LCN is a tolerance
 // (ATen's conv2d summation order is unspecified): every output within 1e-5 |b| + 1e-6 of the reference's
@@ -165,6 +165,10 @@ __global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__
                                                        float* __restrict__ stds, int H, int W, float eps) {
   constexpr int ROWS = 256 / TW;                                   // thread rows of the block
   constexpr int TRr = TH + 2 * R, TCc = TW + 2 * R, NTAP = 2 * R + 1;
+  // sliding sums from radius 4 on; below, a window is at most 7 taps a side -- a fresh sum costs no more, and the residue a
+  // bright sample leaves in a running sum (one ulp of ITS square) is divided by only 9 .. 49 taps: 3.5e-6 of std on the
+  // variance floor at radius 1 (tools/fuzz_lcn.py)
+  constexpr bool SLIDE = R >= 4;
   __shared__ float rs1[TRr][TW], rs2[TRr][TW];                     // row sums of x and x^2
   __shared__ float tile[TRr][TCc];                                 // reflect-padded input
   const int tid = threadIdx.x;
@@ -238,8 +242,17 @@ __global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__
     rs2[r][c0] = s2;
 #pragma unroll
     for (int o = 1; o < kLcnHC; ++o) {
-      s1 = (s1 + v[o + NTAP - 1]) - v[o - 1];
-      s2 = (s2 + q[o + NTAP - 1]) - q[o - 1];
+      if constexpr (SLIDE) {
+        s1 = (s1 + v[o + NTAP - 1]) - v[o - 1];
+        s2 = (s2 + q[o + NTAP - 1]) - q[o - 1];
+      } else {
+        s1 = s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) {
+          s1 += v[o + k];
+          s2 += q[o + k];
+        }
+      }
       rs1[r][c0 + o] = s1;
       rs2[r][c0 + o] = s2;
     }
@@ -265,8 +278,17 @@ __global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     if (i > 0) {
-      s1 = (s1 + c1[i + NTAP - 1]) - c1[i - 1];
-      s2 = (s2 + c2[i + NTAP - 1]) - c2[i - 1];
+      if constexpr (SLIDE) {
+        s1 = (s1 + c1[i + NTAP - 1]) - c1[i - 1];
+        s2 = (s2 + c2[i + NTAP - 1]) - c2[i - 1];
+      } else {
+        s1 = s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k) {
+          s1 += c1[i + k];
+          s2 += c2[i + k];
+        }
+      }
     }
     const int r = ty * RPT + i, h = h_lo + r;
     if (w >= W || h >= H) continue;
@@ -286,10 +308,17 @@ __global__ __launch_bounds__(256) void lcn_fast_kernel(const float* __restrict__
 #endif
 
 int lcn_fast_f32(const float* x, float* y, float* stds, int N, int H, int W, int radius, float eps, hipStream_t stream) {
-  if (radius != 5) return CTD_ERR_UNSUPPORTED;                     // the radius the reference uses (exp_synph.py:41)
+  // radius 5 is the one the reference uses (exp_synph.py:41) and the one the tile shape was tuned for; 1 .. 7 share the kernel
   constexpr int TW = CTD_LCN_FAST_TW, TH = CTD_LCN_FAST_TH;
   dim3 grid(ceil_div(W, TW), ceil_div(H, TH), N), block(256);
-  hipLaunchKernelGGL((lcn_fast_kernel<5, TW, TH>), grid, block, 0, stream, x, y, stds, H, W, eps);
+  switch (radius) {
+#define CTD_LCN_FAST_CASE(R) \
+    case R: hipLaunchKernelGGL((lcn_fast_kernel<R, TW, TH>), grid, block, 0, stream, x, y, stds, H, W, eps); break;
+    CTD_LCN_FAST_CASE(1) CTD_LCN_FAST_CASE(2) CTD_LCN_FAST_CASE(3) CTD_LCN_FAST_CASE(4)
+    CTD_LCN_FAST_CASE(5) CTD_LCN_FAST_CASE(6) CTD_LCN_FAST_CASE(7)
+#undef CTD_LCN_FAST_CASE
+    default: return CTD_ERR_UNSUPPORTED;
+  }
   CTD_LAUNCH_CHECK();
   return CTD_OK;
 }

@@ -347,7 +347,7 @@ def lcn(data, radius, epsilon, algo=None):
     """data [N,1,H,W] f32 -> ((data - avg) / std, std), std = sqrt(E[x^2] - avg^2 + 1e-6) + epsilon,
     box statistics over a (2*radius+1)^2 reflect-padded window.  Not differentiable (the reference
     only ever applies it to input images, exp_synph.py:84-91).
-    algo (additive): 'exact' (default: f64 box sums, bit-identical to the oracle) | 'fast' (radius 5: f32 sliding sums of
+    algo (additive): 'exact' (default: f64 box sums, bit-identical to the oracle) | 'fast' (radius 1 .. 7, other radii run 'exact': f32 sliding sums of
     tile-centred samples, within 1e-5 |b| + 1e-6 of 'exact' and of the reference -- whose own summation order is unspecified --
     except on the variance floor of flat non-zero levels, see include/ctd_hip.h)."""
     _check(data, "data", (torch.float32,))
@@ -362,7 +362,7 @@ def lcn(data, radius, epsilon, algo=None):
     algo = algo or "exact"
     if algo not in ("exact", "fast"):
         raise RuntimeError("unknown algo %r" % (algo,))
-    fn = _lib.lib().ctd_lcn_fast_f32 if (algo == "fast" and int(radius) == 5) else _lib.lib().ctd_lcn_f32
+    fn = _lib.lib().ctd_lcn_fast_f32 if (algo == "fast" and 1 <= int(radius) <= 7) else _lib.lib().ctd_lcn_f32
     st = fn(_ptr(data), _ptr(y), _ptr(std), N, H, W, int(radius), float(epsilon), dev.index, _stream(dev))
     _lib.check(st, "lcn")
     return y, std

@@ -190,7 +190,7 @@ int ctd_costvol_fast_f32(const float* im, const float* pattern, long pattern_fra
  * -------------------------------------------------------------------------------------- */
 int ctd_lcn_f32(const float* x, float* y, float* std_out, int N, int H, int W, int radius,
                 float eps, int device, void* stream);
-/* tolerance-level variant (radius 5 only, else CTD_ERR_UNSUPPORTED): f32 sliding-window box sums instead of f64 ones, of
+/* tolerance-level variant (radius 1 .. 7, else CTD_ERR_UNSUPPORTED): f32 sliding-window box sums instead of f64 ones, of
  * samples centred per 64 x 16 tile (0 where the tile reaches zero, else the tile's mean).  Every output within
  * 1e-5 |b| + 1e-6 of ctd_lcn_f32 and of the reference's networks.LCN (whose conv2d summation order is unspecified) where a
  * window's variance is not small against its mean square about that centre -- uniform / textured frames, frames with a DC

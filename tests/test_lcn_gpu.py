@@ -68,9 +68,21 @@ def test_lcn_fast_vs_reference_golden(te):
         y, s = te.lcn(dev(g["x_%d" % k]), 5, 0.05, algo="fast")
         assert_close(s.cpu().numpy(), g["std_%d" % k], what="std %d" % k)
         assert_close(y.cpu().numpy(), g["y_%d" % k], rtol=2e-5, atol=2e-6, what="lcn %d" % k)
-    # other radii run the f64 kernel
+    # the other radii the f32 kernel serves (1 .. 7)
     y, s = te.LCN(2, 0.1, algo="fast")(dev(g["x_r2"]))
     assert_close(s.cpu().numpy(), g["std_r2"], what="std r2")
+    assert_close(y.cpu().numpy(), g["y_r2"], rtol=2e-5, atol=2e-6, what="lcn r2")
+
+
+@pytest.mark.parametrize("radius", [1, 3, 4, 6, 7, 9])
+def test_lcn_fast_other_radii(te, oracle, radius):
+    """algo='fast' for the radii 1 .. 7 (same kernel, tap loops of another length) against the oracle; 9 runs the f64 kernel"""
+    rs = np.random.RandomState(radius)
+    x = (rs.rand(2, 1, 45, 150) * 3 + rs.randn(2, 1, 1, 1)).astype(np.float32)
+    y0, s0 = oracle.lcn(x, radius, 0.05)
+    y, s = te.lcn(dev(x), radius, 0.05, algo="fast")
+    assert_close(s.cpu().numpy(), s0, what="fast std r%d" % radius)
+    assert_close(y.cpu().numpy(), y0, what="fast lcn r%d" % radius)
 
 
 def test_lcn_errors(te):

@@ -9,7 +9,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
-    r = int(rs.choice([1, 2, 5, 5, 5, 7]))
+    r = int(rs.choice([1, 2, 3, 4, 5, 5, 5, 6, 7]))
     N = int(rs.randint(1, 5)); H = int(rs.randint(r + 1, 150)); W = int(rs.randint(r + 1, 300))
     kind = case % 4
     if kind == 0:                                            # uniform with a DC level per frame
@@ -23,12 +23,15 @@ for case in range(cases):
         xn = np.round(rs.rand(N, 1, H, W) * 2) * 0.25 + 0.003 * rs.randn(N, 1, H, W)   # good as another's only up to E[x^2] 2^-24)
     x = torch.from_numpy(xn.astype(np.float32)).cuda()
     y, s = te.lcn(x, r, 0.05)
-    if r == 5 and kind != 3:                                 # algo='fast' against the f64 kernel, the suite's tolerance
+    if kind != 3:                                 # algo='fast' against the f64 kernel, the suite's tolerance
         yf, sf = te.lcn(x, r, 0.05, algo="fast")
         # (kind 2 -- a low-noise level with windows that hold no bright sample -- sits on the variance floor of 1e-6: an f32
         # one-pass variance is good to E[(x - c)^2] * 2^-24 * (roundings) there, 3e-6 absolute of std at these levels)
         atol = 3e-6 if kind == 2 else 1e-6
-        if not bool(((yf - y).abs() <= y.abs() * 1e-5 + atol).all() and ((sf - s).abs() <= s.abs() * 1e-5 + atol).all()):
+        # (windows of 9 .. 81 samples have, now and then, a variance far below their mean square: there the exact kernel's
+        # own f32 tail E[x^2] - avg^2 is as noisy as any other order's -- 5e-5 relative below radius 5)
+        rtol = 1e-5 if r >= 5 else 5e-5
+        if not bool(((yf - y).abs() <= y.abs() * rtol + atol).all() and ((sf - s).abs() <= s.abs() * rtol + atol).all()):
             bad += 1
             print("case %d N=%d H=%d W=%d: fast vs exact y %g std %g" % (case, N, H, W, float((yf - y).abs().max()), float((sf - s).abs().max())), flush=True)
     xd = x.double(); n = float((2 * r + 1) ** 2)
