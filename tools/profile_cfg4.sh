@@ -47,10 +47,12 @@ for f in glob.glob(out + "/pmc4_*/*/*counter_collection.csv"):
         if "ctd::" not in k:
             continue
         agg[(k, grids.get(row["Dispatch_Id"], "?"))][row["Counter_Name"]].append(float(row["Counter_Value"]))
-# per kernel: the launch shape with the most bytes (the 1024 x 1024 frame, not the one-image set-up launches)
+# per kernel: the launch shape with the most LAUNCHES (the timed one-frame step and its settle loop -- not the one-image
+# set-up launches, and not the two-frame call of the `ncc_two_frames_per_call` leg, which moves twice the bytes: until round 5
+# the shape with the most bytes was taken, i.e. the two-frame call's)
 best = {}
 for (k, g), cs in agg.items():
-    tot = sum(sum(v) / len(v) for v in cs.values())
+    tot = max(len(v) for v in cs.values())
     if k not in best or tot > best[k][0]:
         best[k] = (tot, g, cs)
 summ = {}
