@@ -3,14 +3,14 @@
 // Replaces, for the frames of a fused call (ctd_lcn_xcorrvol_argmax_f32), the two LDS-tiled launches lcn_kernel /
 // lcn_fast_kernel (lcn.hip; LCN.tforward, model/networks.py:507-533) and ncc_prepass_kernel (ncc_fast.hip; the window
 // mean / deviation of XCorrVolFunctor, torchext/ext/ext.h:143-181, hoisted out of the disparity loop).  Both of those
-// are tiles with two barriers and a halo of 10 / 8 pixels each way, and both live on occupancy;
-// here a wavefront owns a strip of 256 columns (lane = 4 adjacent columns: 16-byte loads and stores) and marches down
-// a band of rows with everything it needs of earlier rows in registers and its own LDS ring -- no tile phases, no
-// second launch, and the LCN output feeds the 9 x 9 statistics without a trip through memory.  A workgroup is that
-// CONSUMER wavefront and a LOADER wavefront that streams the raw rows global -> LDS (LDS-DMA, kLsPF rows ahead) and is
-// the only one that ever waits for a load: on gfx950 loads and stores retire in order on one counter, so a wavefront
-// that did both would wait for its newest stores every row (the same split as the volume kernels of ncc_fast.hip);
-// the two meet at one s_barrier per row.
+// are tiles with two barriers and a halo of 10 / 8 pixels each way, and both live on occupancy (docs/history.md);
+// here a workgroup owns a strip of 256 columns (lane = 4 adjacent columns: 16-byte loads and stores) and marches down
+// a band of rows with everything it needs of earlier rows in registers and LDS rings -- no tile phases, no second
+// launch, and the LCN output feeds the 9 x 9 statistics without a trip through memory.  Its three wavefronts are two
+// pipeline stages (LCN | statistics, one row apart) and a LOADER that streams the raw rows global -> LDS (LDS-DMA,
+// kLsPF rows ahead) and is the only one that ever waits for a load: on gfx950 loads and stores retire in order on one
+// counter, so a wavefront that did both would wait for its newest stores every row (the same split as the volume
+// kernels of ncc_fast.hip); the three meet at one s_barrier per row.
 //   raw row u  --vertical 11-row sums V (sliding, per column)-->  horizontal 11-column sums (DPP wave shifts)
 //              --> y = (x - avg) / std of row u - 5 --> stored (LCN output + the matcher's padded copy)
 //              --> vertical 9-row sums of y, y^2 as 3 + 3 + 3 (no running sum: every window is a fresh <= 4-level sum)
