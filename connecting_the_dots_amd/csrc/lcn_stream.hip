@@ -408,7 +408,9 @@ int lcn_stream_f32(const float* x, float* y, float* stds, int N, int H, int W, f
   int target = 1024, dev = 0, n_cu = 0;
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
     target = 4 * n_cu;
-  if (const char* e = getenv("CTD_LS_WAVES")) target = atoi(e);          // (experiment knob of tools/r5_prof_fused.sh)
+#ifdef CTD_LS_KNOBS   // (variant builds only: the workgroup-count sweep of tools/r5_prof_fused.sh)
+  if (const char* e = getenv("CTD_LS_WAVES")) target = atoi(e);
+#endif
   int n_bands = target / (N * a.n_strips);
   if (n_bands > H / 8) n_bands = H / 8;
   if (n_bands < 1) n_bands = 1;
